@@ -1,0 +1,191 @@
+"""ctypes binding of libf2cnn_hip.so (C ABI: include/f2cnn_hip.h).
+
+There is no CPU fallback: if the library is missing it is built with hipcc; if that fails, or no
+gfx950 device is present when a context is requested, an exception is raised.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import build as _build
+
+F2_OK, F2_ERR_INVALID, F2_ERR_HIP, F2_ERR_UNSUPPORTED, F2_ERR_NOMEM, F2_ERR_NONPOSITIVE = 0, -1, -2, -3, -4, -5
+MEM_HOST, MEM_DEVICE = 0, 1
+WAVE_I16, WAVE_F64 = 0, 1
+FFT_F32, FFT_F64 = 0, 1
+
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_P = C.POINTER
+
+# name -> (restype, argtypes); mirrors include/f2cnn_hip.h one to one
+SIGNATURES = {
+    "f2_version": (_i, []),
+    "f2_device_count": (_i, [_P(_i)]),
+    "f2_ctx_create": (_i, [_i, _P(_vp)]),
+    "f2_ctx_destroy": (_i, [_vp]),
+    "f2_ctx_synchronize": (_i, [_vp]),
+    "f2_ctx_set_stream": (_i, [_vp, _vp]),
+    "f2_ctx_get_stream": (_vp, [_vp]),
+    "f2_last_error": (C.c_char_p, [_vp]),
+    "f2_dev_malloc": (_i, [_vp, C.c_size_t, _P(_vp)]),
+    "f2_dev_free": (_i, [_vp, _vp]),
+    "f2_dev_memset": (_i, [_vp, _vp, _i, C.c_size_t]),
+    "f2_memcpy_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "f2_memcpy_d2h": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "f2_event_create": (_i, [_vp, _P(_vp)]),
+    "f2_event_destroy": (_i, [_vp, _vp]),
+    "f2_event_record": (_i, [_vp, _vp]),
+    "f2_event_elapsed_ms": (_i, [_vp, _vp, _vp, _P(C.c_float)]),
+    "f2_erb_filterbank_batch": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i]),
+    "f2_envelope_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _i, _vp, _i]),
+    "f2_filterbank_envelope_fused": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _vp, _i]),
+    "f2_gather_windows": (_i, [_vp, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _vp, _i]),
+    "f2_cnn_create": (_i, [_vp, _P(_vp), _i, _i, _P(_vp)]),
+    "f2_cnn_destroy": (_i, [_vp, _vp]),
+    "f2_cnn_forward": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i]),
+    "f2_eval_utterance": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _i, _i, _d, _i, _i, _i, _vp, _vp, _vp, _P(_i64), _i]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class F2Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libf2cnn_hip error {code}: {msg}")
+        self.code = code
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load(build_if_missing=True):
+    """dlopen the library (building it first if it is absent) and declare every signature."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            if not build_if_missing:
+                raise FileNotFoundError(f"{path} is missing: run `python -m f2cnn_amd.build` (needs hipcc)")
+            _build.build_library()
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+        return lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a  # int device pointer
+
+
+class Context:
+    """One f2_ctx: a device, a stream and its scratch memory. Not thread-safe (one host thread per context)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.f2_ctx_create(int(device), C.byref(h))
+        if rc != F2_OK:
+            raise F2Error(rc, self.lib.f2_last_error(None).decode())
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.f2_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != F2_OK:
+            raise F2Error(rc, self.lib.f2_last_error(self.handle).decode())
+
+    # ---- plumbing ----
+    def synchronize(self):
+        self.check(self.lib.f2_ctx_synchronize(self.handle))
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.f2_ctx_set_stream(self.handle, stream_ptr))
+
+    def malloc(self, nbytes):
+        p = _vp()
+        self.check(self.lib.f2_dev_malloc(self.handle, int(nbytes), C.byref(p)))
+        return p.value or 0
+
+    def free(self, dptr):
+        self.check(self.lib.f2_dev_free(self.handle, dptr))
+
+    def memset(self, dptr, value, nbytes):
+        self.check(self.lib.f2_dev_memset(self.handle, dptr, value, int(nbytes)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.f2_memcpy_h2d(self.handle, dptr, arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        self.check(self.lib.f2_memcpy_d2h(self.handle, arr.ctypes.data, dptr, arr.nbytes))
+
+    def event(self):
+        e = _vp()
+        self.check(self.lib.f2_event_create(self.handle, C.byref(e)))
+        return e
+
+    def record(self, ev):
+        self.check(self.lib.f2_event_record(self.handle, ev))
+
+    def elapsed_ms(self, e0, e1):
+        ms = C.c_float()
+        self.check(self.lib.f2_event_elapsed_ms(self.handle, e0, e1, C.byref(ms)))
+        return ms.value
+
+    def destroy_event(self, ev):
+        self.check(self.lib.f2_event_destroy(self.handle, ev))
+
+    # ---- ops (data pointers: numpy arrays with mem_space HOST, or int device pointers) ----
+    def erb_filterbank_batch(self, wave, wave_dtype, offsets, coefs, B, Cn, gfb, mem_space):
+        self.check(self.lib.f2_erb_filterbank_batch(self.handle, _ptr(wave), wave_dtype, _ptr(offsets), _ptr(coefs),
+                                                    B, Cn, _ptr(gfb), mem_space))
+
+    def envelope_batch(self, gfb, offsets, B, Cn, lpf, cutoff, precision, env, mem_space):
+        self.check(self.lib.f2_envelope_batch(self.handle, _ptr(gfb), _ptr(offsets), B, Cn, int(bool(lpf)),
+                                              float(cutoff), precision, _ptr(env), mem_space))
+
+    def filterbank_envelope_fused(self, wave, wave_dtype, offsets, coefs, B, Cn, lpf, cutoff, precision, env, gfb,
+                                  mem_space):
+        self.check(self.lib.f2_filterbank_envelope_fused(self.handle, _ptr(wave), wave_dtype, _ptr(offsets),
+                                                         _ptr(coefs), B, Cn, int(bool(lpf)), float(cutoff), precision,
+                                                         _ptr(env), _ptr(gfb), mem_space))
+
+    def gather_windows(self, env, Cn, N, centers, n_windows, radius, step, normalize, out, mem_space):
+        self.check(self.lib.f2_gather_windows(self.handle, _ptr(env), Cn, N, _ptr(centers), n_windows, radius, step,
+                                              int(bool(normalize)), _ptr(out), mem_space))
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context per device (device defaults to $F2CNN_DEVICE or 0)."""
+    if device is None:
+        device = int(os.environ.get("F2CNN_DEVICE", "0"))
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx.handle is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

@@ -1,0 +1,350 @@
+// C-ABI entry points of libf2cnn_hip.so: context, memory/timing helpers, and the host/device
+// pointer handling around the kernel launchers. See include/f2cnn_hip.h for the contract.
+#include "f2_internal.h"
+
+char g_f2_err[512] = {0};
+
+int f2_fail(f2_ctx* ctx, int code, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_f2_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int f2_reserve(f2_ctx* ctx, f2_scratch& s, size_t bytes) {
+    if (bytes <= s.bytes) return F2_OK;
+    if (s.ptr) {
+        // the old block may still be in use by work queued on the stream
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        F2_HIP(ctx, hipFree(s.ptr));
+        s.ptr = nullptr;
+        s.bytes = 0;
+    }
+    size_t want = (bytes + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&s.ptr, want);
+    if (e != hipSuccess) {
+        s.ptr = nullptr;
+        return f2_fail(ctx, F2_ERR_NOMEM, "hipMalloc(%zu) -> %s", want, hipGetErrorString(e));
+    }
+    s.bytes = want;
+    return F2_OK;
+}
+
+extern "C" {
+
+int f2_version(void) { return 100; }
+
+int f2_device_count(int* count) {
+    if (!count) return f2_fail(nullptr, F2_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return f2_fail(nullptr, F2_ERR_HIP, "hipGetDeviceCount -> %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return F2_OK;
+}
+
+int f2_ctx_create(int device, f2_ctx** out) {
+    if (!out) return f2_fail(nullptr, F2_ERR_INVALID, "ctx out pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return f2_fail(nullptr, F2_ERR_HIP, "no HIP device available (%s)",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n) return f2_fail(nullptr, F2_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    f2_ctx* ctx = new f2_ctx();
+    ctx->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->host_flags, 64, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        f2_fail(nullptr, F2_ERR_HIP, "context setup on device %d -> %s", device, hipGetErrorString(e));
+        delete ctx;
+        return F2_ERR_HIP;
+    }
+    ctx->num_cus = prop.multiProcessorCount;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        f2_fail(nullptr, F2_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 only", device,
+                prop.gcnArchName);
+        (void)hipStreamDestroy(ctx->stream);
+        (void)hipHostFree(ctx->host_flags);
+        delete ctx;
+        return F2_ERR_UNSUPPORTED;
+    }
+    int rc = f2_reserve(ctx, ctx->flags, 64);
+    if (rc != F2_OK) {
+        memcpy(g_f2_err, ctx->err, sizeof(g_f2_err));
+        (void)hipStreamDestroy(ctx->stream);
+        (void)hipHostFree(ctx->host_flags);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return F2_OK;
+}
+
+int f2_ctx_destroy(f2_ctx* ctx) {
+    if (!ctx) return F2_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    f2_scratch* all[] = {&ctx->coefs, &ctx->offsets, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux,
+                         &ctx->work,  &ctx->work2,   &ctx->tw32,     &ctx->tw64,      &ctx->flags};
+    for (f2_scratch* s : all)
+        if (s->ptr) (void)hipFree(s->ptr);
+    if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return F2_OK;
+}
+
+int f2_ctx_synchronize(f2_ctx* ctx) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F2_OK;
+}
+
+int f2_ctx_set_stream(f2_ctx* ctx, void* hip_stream) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) F2_HIP(ctx, hipStreamDestroy(ctx->stream));
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        F2_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return F2_OK;
+}
+
+void* f2_ctx_get_stream(f2_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+const char* f2_last_error(f2_ctx* ctx) { return ctx ? ctx->err : g_f2_err; }
+
+int f2_dev_malloc(f2_ctx* ctx, size_t bytes, void** dptr) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, dptr, F2_ERR_INVALID, "dptr is NULL");
+    *dptr = nullptr;
+    if (bytes == 0) return F2_OK;
+    F2_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) return f2_fail(ctx, F2_ERR_NOMEM, "hipMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
+    return F2_OK;
+}
+
+int f2_dev_free(f2_ctx* ctx, void* dptr) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    if (!dptr) return F2_OK;
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    F2_HIP(ctx, hipFree(dptr));
+    return F2_OK;
+}
+
+int f2_dev_memset(f2_ctx* ctx, void* dptr, int value, size_t bytes) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    if (bytes == 0) return F2_OK;
+    F2_CHECK(ctx, dptr, F2_ERR_INVALID, "dptr is NULL");
+    F2_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return F2_OK;
+}
+
+int f2_memcpy_h2d(f2_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    if (bytes == 0) return F2_OK;
+    F2_CHECK(ctx, dst && src, F2_ERR_INVALID, "null pointer in h2d copy");
+    F2_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F2_OK;
+}
+
+int f2_memcpy_d2h(f2_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    if (bytes == 0) return F2_OK;
+    F2_CHECK(ctx, dst && src, F2_ERR_INVALID, "null pointer in d2h copy");
+    F2_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F2_OK;
+}
+
+int f2_event_create(f2_ctx* ctx, void** event) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, event, F2_ERR_INVALID, "event out pointer is NULL");
+    hipEvent_t ev;
+    F2_HIP(ctx, hipEventCreate(&ev));
+    *event = (void*)ev;
+    return F2_OK;
+}
+
+int f2_event_destroy(f2_ctx* ctx, void* event) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    if (event) F2_HIP(ctx, hipEventDestroy((hipEvent_t)event));
+    return F2_OK;
+}
+
+int f2_event_record(f2_ctx* ctx, void* event) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, event, F2_ERR_INVALID, "event is NULL");
+    F2_HIP(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+    return F2_OK;
+}
+
+int f2_event_elapsed_ms(f2_ctx* ctx, void* start, void* stop, float* ms) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, start && stop && ms, F2_ERR_INVALID, "null argument");
+    F2_HIP(ctx, hipEventSynchronize((hipEvent_t)stop));
+    F2_HIP(ctx, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return F2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// argument checking shared by the batched DSP entry points
+// ------------------------------------------------------------------------------------------------
+static int check_batch(f2_ctx* ctx, const int64_t* offsets, int B, int C, int mem_space) {
+    F2_CHECK(ctx, B >= 0 && C >= 0, F2_ERR_INVALID, "negative batch (B=%d) or channel count (C=%d)", B, C);
+    F2_CHECK(ctx, mem_space == F2_MEM_HOST || mem_space == F2_MEM_DEVICE, F2_ERR_INVALID, "bad mem_space %d", mem_space);
+    F2_CHECK(ctx, offsets, F2_ERR_INVALID, "offsets is NULL");
+    F2_CHECK(ctx, offsets[0] == 0, F2_ERR_INVALID, "offsets[0] must be 0");
+    for (int b = 0; b < B; ++b)
+        F2_CHECK(ctx, offsets[b + 1] >= offsets[b], F2_ERR_INVALID, "offsets must be non-decreasing (b=%d)", b);
+    return F2_OK;
+}
+
+static int upload_offsets(f2_ctx* ctx, const int64_t* offsets, int B) {
+    if (ctx->offsets_host.size() == (size_t)(B + 1) &&
+        memcmp(ctx->offsets_host.data(), offsets, sizeof(int64_t) * (size_t)(B + 1)) == 0)
+        return F2_OK;  // same batch shape as the previous call: the device copy is still valid
+    ctx->offsets_host.clear();
+    F2_TRY(f2_reserve(ctx, ctx->offsets, sizeof(int64_t) * (size_t)(B + 1)));
+    F2_HIP(ctx, hipMemcpyAsync(ctx->offsets.ptr, offsets, sizeof(int64_t) * (size_t)(B + 1), hipMemcpyHostToDevice,
+                               ctx->stream));
+    // the host array belongs to the caller: do not return before the copy has read it
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->offsets_host.assign(offsets, offsets + B + 1);
+    return F2_OK;
+}
+
+static int upload_coefs(f2_ctx* ctx, const double* coefs, int C) {
+    if (ctx->coefs_host.size() == (size_t)C * 10 &&
+        memcmp(ctx->coefs_host.data(), coefs, sizeof(double) * 10 * (size_t)C) == 0)
+        return F2_OK;
+    ctx->coefs_host.clear();
+    F2_TRY(f2_reserve(ctx, ctx->coefs, sizeof(double) * 10 * (size_t)C));
+    F2_HIP(ctx, hipMemcpyAsync(ctx->coefs.ptr, coefs, sizeof(double) * 10 * (size_t)C, hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->coefs_host.assign(coefs, coefs + (size_t)C * 10);
+    return F2_OK;
+}
+
+static size_t wave_elem(int wave_dtype) { return wave_dtype == F2_WAVE_I16 ? 2 : 8; }
+
+int f2_erb_filterbank_batch(f2_ctx* ctx, const void* wave, int wave_dtype, const int64_t* offsets,
+                            const double* coefs, int B, int C, double* gfb, int mem_space) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_HIP(ctx, hipSetDevice(ctx->device));
+    F2_CHECK(ctx, wave_dtype == F2_WAVE_I16 || wave_dtype == F2_WAVE_F64, F2_ERR_INVALID, "bad wave_dtype %d", wave_dtype);
+    F2_TRY(check_batch(ctx, offsets, B, C, mem_space));
+    const int64_t total = offsets[B];
+    if (B == 0 || C == 0 || total == 0) return F2_OK;
+    F2_CHECK(ctx, wave && coefs && gfb, F2_ERR_INVALID, "null data pointer");
+    F2_TRY(upload_offsets(ctx, offsets, B));
+    F2_TRY(upload_coefs(ctx, coefs, C));
+    const void* d_wave = wave;
+    double* d_gfb = gfb;
+    const size_t out_bytes = sizeof(double) * (size_t)C * (size_t)total;
+    if (mem_space == F2_MEM_HOST) {
+        F2_TRY(f2_reserve(ctx, ctx->stage_in, wave_elem(wave_dtype) * (size_t)total));
+        F2_TRY(f2_reserve(ctx, ctx->stage_out, out_bytes));
+        F2_HIP(ctx, hipMemcpyAsync(ctx->stage_in.ptr, wave, wave_elem(wave_dtype) * (size_t)total, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        d_wave = ctx->stage_in.ptr;
+        d_gfb = (double*)ctx->stage_out.ptr;
+    }
+    F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
+                                (const double*)ctx->coefs.ptr, B, C, d_gfb));
+    if (mem_space == F2_MEM_HOST) {
+        F2_HIP(ctx, hipMemcpyAsync(gfb, d_gfb, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return F2_OK;
+}
+
+int f2_envelope_batch(f2_ctx* ctx, const double* gfb, const int64_t* offsets, int B, int C, int lpf,
+                      double cutoff_hz, int fft_precision, double* env, int mem_space) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_HIP(ctx, hipSetDevice(ctx->device));
+    F2_CHECK(ctx, fft_precision == F2_FFT_F32 || fft_precision == F2_FFT_F64, F2_ERR_INVALID, "bad fft_precision %d", fft_precision);
+    F2_CHECK(ctx, !lpf || (cutoff_hz > 0 && cutoff_hz < 8000), F2_ERR_INVALID, "cutoff %g Hz outside (0, 8000)", cutoff_hz);
+    F2_TRY(check_batch(ctx, offsets, B, C, mem_space));
+    const int64_t total = offsets[B];
+    if (B == 0 || C == 0 || total == 0) return F2_OK;
+    F2_CHECK(ctx, gfb && env, F2_ERR_INVALID, "null data pointer");
+    F2_TRY(upload_offsets(ctx, offsets, B));
+    const double* d_gfb = gfb;
+    double* d_env = env;
+    const size_t bytes = sizeof(double) * (size_t)C * (size_t)total;
+    if (mem_space == F2_MEM_HOST) {
+        F2_TRY(f2_reserve(ctx, ctx->stage_out, bytes));
+        F2_HIP(ctx, hipMemcpyAsync(ctx->stage_out.ptr, gfb, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_gfb = d_env = (double*)ctx->stage_out.ptr;  // in place on the device
+    }
+    F2_TRY(f2_launch_envelope(ctx, d_gfb, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz,
+                              fft_precision, d_env));
+    if (mem_space == F2_MEM_HOST) {
+        F2_HIP(ctx, hipMemcpyAsync(env, d_env, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return F2_OK;
+}
+
+int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, const int64_t* offsets,
+                                 const double* coefs, int B, int C, int lpf, double cutoff_hz,
+                                 int fft_precision, double* env, double* gfb_or_null, int mem_space) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_HIP(ctx, hipSetDevice(ctx->device));
+    F2_CHECK(ctx, wave_dtype == F2_WAVE_I16 || wave_dtype == F2_WAVE_F64, F2_ERR_INVALID, "bad wave_dtype %d", wave_dtype);
+    F2_CHECK(ctx, fft_precision == F2_FFT_F32 || fft_precision == F2_FFT_F64, F2_ERR_INVALID, "bad fft_precision %d", fft_precision);
+    F2_CHECK(ctx, !lpf || (cutoff_hz > 0 && cutoff_hz < 8000), F2_ERR_INVALID, "cutoff %g Hz outside (0, 8000)", cutoff_hz);
+    F2_TRY(check_batch(ctx, offsets, B, C, mem_space));
+    const int64_t total = offsets[B];
+    if (B == 0 || C == 0 || total == 0) return F2_OK;
+    F2_CHECK(ctx, wave && coefs && env, F2_ERR_INVALID, "null data pointer");
+    F2_TRY(upload_offsets(ctx, offsets, B));
+    F2_TRY(upload_coefs(ctx, coefs, C));
+    const size_t bytes = sizeof(double) * (size_t)C * (size_t)total;
+    const void* d_wave = wave;
+    double* d_env = env;
+    double* d_gfb = gfb_or_null;
+    if (mem_space == F2_MEM_HOST) {
+        F2_TRY(f2_reserve(ctx, ctx->stage_in, wave_elem(wave_dtype) * (size_t)total));
+        F2_TRY(f2_reserve(ctx, ctx->stage_out, bytes));
+        if (gfb_or_null) F2_TRY(f2_reserve(ctx, ctx->stage_aux, bytes));
+        F2_HIP(ctx, hipMemcpyAsync(ctx->stage_in.ptr, wave, wave_elem(wave_dtype) * (size_t)total, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        d_wave = ctx->stage_in.ptr;
+        d_env = (double*)ctx->stage_out.ptr;
+        d_gfb = gfb_or_null ? (double*)ctx->stage_aux.ptr : nullptr;
+    }
+    // v0 of the fused path: the filterbank writes straight into the ENV buffer (or the GFB buffer when
+    // that output is wanted) and the envelope kernel runs in place / from it, so no third buffer and
+    // no host round trip; both launches are queued back to back on the context's stream.
+    double* k1_out = d_gfb ? d_gfb : d_env;
+    F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
+                                (const double*)ctx->coefs.ptr, B, C, k1_out));
+    F2_TRY(f2_launch_envelope(ctx, k1_out, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz,
+                              fft_precision, d_env));
+    if (mem_space == F2_MEM_HOST) {
+        F2_HIP(ctx, hipMemcpyAsync(env, d_env, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (gfb_or_null) F2_HIP(ctx, hipMemcpyAsync(gfb_or_null, d_gfb, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return F2_OK;
+}
+
+}  // extern "C"

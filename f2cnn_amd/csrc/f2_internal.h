@@ -1,0 +1,85 @@
+// Internal declarations shared by the translation units of libf2cnn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/f2cnn_hip.h"
+
+struct f2_scratch {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct f2_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    int num_cus = 0;
+    char err[512] = {0};
+    // grow-only device scratch areas (never freed before ctx destroy; stream-ordered reuse only)
+    f2_scratch coefs;      // filter coefficients of the current call
+    f2_scratch offsets;    // ragged offsets of the current call
+    f2_scratch stage_in;   // F2_MEM_HOST staging
+    f2_scratch stage_out;
+    f2_scratch stage_aux;
+    f2_scratch work;       // intermediates (GFB between K1 and K2, activations, ...)
+    f2_scratch work2;
+    f2_scratch tw32, tw64; // FFT twiddle tables
+    int tw32_log2 = -1, tw64_log2 = -1;
+    std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
+    std::vector<double> coefs_host;     // what ctx->coefs currently holds
+    f2_scratch flags;      // small device words (error flags)
+    int* host_flags = nullptr;  // pinned mirror
+};
+
+struct f2_cnn {
+    int rows = 0, channels = 0, flat = 0;
+    float* blob = nullptr;       // all tensors, device
+    size_t off[12] = {0};        // element offsets of the 12 tensors in `blob`
+};
+
+extern char g_f2_err[512];
+
+int f2_fail(f2_ctx* ctx, int code, const char* fmt, ...);
+int f2_reserve(f2_ctx* ctx, f2_scratch& s, size_t bytes);
+
+#define F2_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return f2_fail((ctx), F2_ERR_HIP, "%s -> %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define F2_CHECK(ctx, cond, code, ...)                        \
+    do {                                                      \
+        if (!(cond)) return f2_fail((ctx), (code), __VA_ARGS__); \
+    } while (0)
+
+#define F2_TRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != F2_OK) return rc_; \
+    } while (0)
+
+static inline int f2_log2_ceil(int64_t n) {
+    int k = 0;
+    while ((int64_t(1) << k) < n) ++k;
+    return k;
+}
+
+// ---- launchers implemented in the kernel translation units (device pointers only) ----
+int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,
+                         const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb);
+int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
+                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env);
+int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const int64_t* d_centers,
+                     int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag);
+int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_scores,
+                  uint8_t* d_labels);

@@ -1,0 +1,143 @@
+/*
+ * f2cnn_hip.h -- C ABI of libf2cnn_hip.so: the MI355X (gfx950) implementation of the F2CNN hot path.
+ *
+ * The reference (tictacmenthe/F2CNN) is pure Python and has no FFI; its boundary for this path is a
+ * set of NumPy-in / NumPy-out functions. Each entry point below replaces the body of one of them
+ * (file:line relative to the reference tree) and is what a ctypes binding in the reference would
+ * call (see INTEGRATION.md for the stub). Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Conventions
+ *   - every function returns F2_OK (0) or a negative f2_status; f2_last_error() gives the text.
+ *   - `mem_space` says whether DATA pointers (wave, gfb, env, x, scores, ...) are host or device
+ *     pointers. Small metadata arrays (offsets, coefs, centers) are ALWAYS host pointers.
+ *   - F2_MEM_HOST calls stage through device memory and return when the result is in the host
+ *     buffer. F2_MEM_DEVICE calls enqueue on the context's stream and return immediately
+ *     (f2_ctx_synchronize() or a stream-ordered consumer to wait).
+ *   - ragged batches: utterance b has n_b = offsets[b+1]-offsets[b] samples; its wave starts at
+ *     wave + offsets[b]; its (C, n_b) C-order float64 matrix starts at out + C*offsets[b]. For a
+ *     uniform batch this is the plain [B][C][N] layout, and each utterance's block is bit-for-bit the
+ *     payload of the reference's .GFB.npy / .ENV1.npy file (row 0 = highest centre frequency).
+ *   - one host thread per context; a context owns one device, one stream and its scratch memory.
+ */
+#ifndef F2CNN_HIP_H
+#define F2CNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct f2_ctx f2_ctx;
+typedef struct f2_cnn f2_cnn;
+
+typedef enum {
+    F2_OK = 0,
+    F2_ERR_INVALID = -1,      /* bad argument (null pointer, negative size, ...)              */
+    F2_ERR_HIP = -2,          /* a HIP runtime call failed (no device, launch failure, ...)    */
+    F2_ERR_UNSUPPORTED = -3,  /* valid request this build cannot serve (e.g. row too long)     */
+    F2_ERR_NOMEM = -4,        /* device or host allocation failed                              */
+    F2_ERR_NONPOSITIVE = -5   /* normalizeInput met a value <= 0 (reference: ValueError)       */
+} f2_status;
+
+enum { F2_MEM_HOST = 0, F2_MEM_DEVICE = 1 };
+enum { F2_WAVE_I16 = 0, F2_WAVE_F64 = 1 };
+/* arithmetic of the Hilbert FFT: F2_FFT_F32 (default; 3.6e-7 max-norm error) or
+ * F2_FFT_F64 (reference-grade, slower). The IIR recurrences are float64 in both. */
+enum { F2_FFT_F32 = 0, F2_FFT_F64 = 1 };
+
+/* ---- library / context -------------------------------------------------------------------- */
+int f2_version(void);
+int f2_device_count(int* count);
+int f2_ctx_create(int device, f2_ctx** ctx);
+int f2_ctx_destroy(f2_ctx* ctx);
+int f2_ctx_synchronize(f2_ctx* ctx);
+/* adopt an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int f2_ctx_set_stream(f2_ctx* ctx, void* hip_stream);
+void* f2_ctx_get_stream(f2_ctx* ctx);
+/* text of the last error on this context (ctx == NULL: last context-less error) */
+const char* f2_last_error(f2_ctx* ctx);
+
+/* ---- device memory + timing helpers (so a host language needs no HIP binding of its own) ---- */
+int f2_dev_malloc(f2_ctx* ctx, size_t bytes, void** dptr);
+int f2_dev_free(f2_ctx* ctx, void* dptr);
+int f2_dev_memset(f2_ctx* ctx, void* dptr, int value, size_t bytes);
+int f2_memcpy_h2d(f2_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int f2_memcpy_d2h(f2_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int f2_event_create(f2_ctx* ctx, void** event);
+int f2_event_destroy(f2_ctx* ctx, void* event);
+int f2_event_record(f2_ctx* ctx, void* event);                 /* on the context's stream */
+int f2_event_elapsed_ms(f2_ctx* ctx, void* start, void* stop, float* ms); /* waits for `stop` */
+
+/* ---- K1: ERB gammatone filterbank ------------------------------------------------------------
+ * Replaces gammatone/filters.py:195-239 erb_filterbank (called from
+ * scripts/processing/GammatoneFiltering.py:42-47 GetFilteredOutputFromArray and
+ * scripts/CNN/Evaluating.py:52), batched over utterances.
+ *   wave     int16 (F2_WAVE_I16) or float64 (F2_WAVE_F64) samples, ragged by `offsets`
+ *   offsets  host, B+1 entries, offsets[0] == 0, non-decreasing
+ *   coefs    host, (C,10) float64 rows [A0,A11,A12,A13,A14,A2,B0,B1,B2,gain] (make_erb_filters)
+ *   gfb      out, float64, C*offsets[B] elements
+ */
+int f2_erb_filterbank_batch(f2_ctx* ctx, const void* wave, int wave_dtype, const int64_t* offsets,
+                            const double* coefs, int B, int C, double* gfb, int mem_space);
+
+/* ---- K2: Hilbert-magnitude envelope + optional 1st-order Butterworth low-pass ----------------
+ * Replaces scripts/processing/EnvelopeExtraction.py:51-67 ExtractEnvelopeFromMatrix (with
+ * paddedHilbert :20-36 and lowPassFilter :39-48), batched. lpf == 0: magnitude only; otherwise
+ * butter(1, cutoff_hz/8000) (8000 hard-coded as in the reference) applied from zero state.
+ *   gfb / env  float64, ragged (C, n_b) blocks as above (env may alias gfb)
+ */
+int f2_envelope_batch(f2_ctx* ctx, const double* gfb, const int64_t* offsets, int B, int C, int lpf,
+                      double cutoff_hz, int fft_precision, double* env, int mem_space);
+
+/* ---- K1+K2 without the float64 GFB round trip through HBM -------------------------------------
+ * `prepare filter` + `prepare envelope` in one call (GammatoneFiltering.py:69-78 followed by
+ * EnvelopeExtraction.py:101-117). gfb_or_null != NULL additionally emits the filterbank output
+ * (needed when .GFB.npy files must be written). */
+int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, const int64_t* offsets,
+                                 const double* coefs, int B, int C, int lpf, double cutoff_hz,
+                                 int fft_precision, double* env, double* gfb_or_null, int mem_space);
+
+/* ---- K3: window gather (+ per-window log min-max normalisation) ------------------------------
+ * Replaces the Python gathers of scripts/processing/InputGenerator.py:73-80 (centers given,
+ * normalize = 0, output cast to float32 as at :83) and scripts/CNN/Evaluating.py:76-80
+ * (centers == NULL: centre_i = radius*step + i for i < n_windows; normalize = 1 applies
+ * scripts/CNN/Training.py:13-28 normalizeInput in float64 before the float32 cast).
+ *   env      (C, N) float64 C-order
+ *   out      (n_windows, 2*radius+1, C) float32
+ * Returns F2_ERR_NONPOSITIVE if normalize != 0 and a window holds a value <= 0 (reference raises
+ * ValueError), F2_ERR_INVALID if a window reaches outside [0, N).
+ */
+int f2_gather_windows(f2_ctx* ctx, const double* env, int C, int64_t N, const int64_t* centers,
+                      int64_t n_windows, int radius, int step, int normalize, float* out, int mem_space);
+
+/* ---- K4: CNN forward ---------------------------------------------------------------------------
+ * Replaces keras model.predict + the label rule of scripts/CNN/Evaluating.py:85-87 for the
+ * architecture built at scripts/CNN/Training.py:93-114.
+ * f2_cnn_create copies 12 host tensors in Keras layouts, in this order:
+ *   conv1 kernel (3,3,1,32) bias (32) | conv2 (3,3,32,32),(32) | conv3 (3,3,32,64),(64) |
+ *   conv4 (3,3,64,64),(64) | dense1 (F,516),(516) | dense2 (516,2),(2),  F = flatten size for (rows, channels)
+ * f2_cnn_forward: x (n, rows, channels) float32 -> scores (n,2) softmax float32 and
+ * labels[i] = scores[i][1] > scores[i][0] (ties -> 0). scores or labels may be NULL.
+ */
+int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channels, f2_cnn** cnn);
+int f2_cnn_destroy(f2_ctx* ctx, f2_cnn* cnn);
+int f2_cnn_forward(f2_ctx* ctx, const f2_cnn* cnn, const float* x, int64_t n, float* scores,
+                   uint8_t* labels, int mem_space);
+
+/* ---- `cnn eval` device pipeline -----------------------------------------------------------------
+ * scripts/CNN/Evaluating.py:42-87 for one utterance with every intermediate kept in HBM:
+ * filterbank -> envelope -> every-sample window gather + normalise -> CNN -> labels.
+ * n_windows_out receives N - (2*radius+1)*step (Evaluating.py:73). env_or_null (C,N) float64,
+ * scores_or_null (n,2), labels_or_null (n) are optional outputs in `mem_space`.
+ */
+int f2_eval_utterance(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave_dtype, int64_t N,
+                      const double* coefs, int C, int lpf, double cutoff_hz, int fft_precision,
+                      int radius, int step, double* env_or_null, float* scores_or_null,
+                      uint8_t* labels_or_null, int64_t* n_windows_out, int mem_space);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F2CNN_HIP_H */

@@ -1,0 +1,71 @@
+"""K1 parity on the GPU, through the C ABI: HIP filterbank vs the oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+
+import f2cnn_oracle as orc
+from conftest import chan_relerr
+from f2cnn_amd import _lib
+from f2cnn_amd.gammatone import filters
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5   # north_star: filterbank outputs within 1e-5 relative (per-channel max-norm)
+
+CASES = ["n1000_c8", "n4096_c8", "n4097_c8", "n16000_c128", "n2500_c128", "impulse_c8", "sine1k_c8",
+         "n1500_f64_c8"]
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_golden(golden, tag):
+    C = 128 if "c128" in tag else 8
+    coefs = golden[f"g1_coefs_{C}"]
+    rows = golden[f"g2_{tag}_rows"]
+    got = filters.erb_filterbank(golden[f"g2_{tag}_wave"], coefs[rows])
+    ref = golden[f"g2_{tag}_gfb"]
+    assert got.shape == ref.shape and got.dtype == np.float64
+    err = chan_relerr(got, ref)
+    assert err <= TOL, err
+    assert err <= 1e-10   # float64 recurrence: far inside the contract
+
+
+@pytest.mark.parametrize("C,N", [(64, 16000), (128, 16000), (128, 777), (5, 33), (130, 1000), (1, 1), (128, 31)])
+def test_vs_oracle(C, N):
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
+    wave = orc.synth_utterance(1234 + C + N, N)
+    got = filters.erb_filterbank(wave, coefs)
+    assert chan_relerr(got, orc.erb_filterbank(wave, coefs)) <= 1e-10
+
+
+def test_ragged_batch_and_empty():
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    lens = [1000, 0, 16000, 1, 4097, 63]
+    waves = [orc.synth_utterance(50 + i, n) for i, n in enumerate(lens)]
+    outs = filters.erb_filterbank_batch(waves, coefs)
+    assert [o.shape for o in outs] == [(128, n) for n in lens]
+    for w, o in zip(waves, outs):
+        if len(w):
+            assert chan_relerr(o, orc.erb_filterbank(w, coefs)) <= 1e-10
+    assert filters.erb_filterbank_batch([], coefs) == []
+    assert filters.erb_filterbank(np.zeros(0, np.int16), coefs).shape == (128, 0)
+
+
+def test_linearity_and_full_size_properties():
+    # size-independent property at a BASELINE-sized row count: filterbank is linear and causal
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    a = orc.synth_utterance(1, 16000).astype(np.float64)
+    b = orc.synth_utterance(2, 16000).astype(np.float64)
+    ya, yb, yab = (filters.erb_filterbank(w, coefs) for w in (a, b, 2 * a - 3 * b))
+    assert chan_relerr(yab, 2 * ya - 3 * yb) <= 1e-9
+    b2 = b.copy()
+    b2[8000:] = 0
+    assert np.array_equal(filters.erb_filterbank(b2, coefs)[:, :8000], yb[:, :8000])
+
+
+def test_bad_arguments():
+    ctx = _lib.default_context()
+    co = np.zeros((4, 10))
+    with pytest.raises(_lib.F2Error):
+        ctx.erb_filterbank_batch(np.zeros(4, np.int16), 7, np.array([0, 4], np.int64), co, 1, 4, np.zeros(16), 0)
+    with pytest.raises(_lib.F2Error):
+        ctx.erb_filterbank_batch(np.zeros(4, np.int16), 0, np.array([1, 4], np.int64), co, 1, 4, np.zeros(16), 0)
+    with pytest.raises(ValueError):
+        filters.erb_filterbank(np.zeros((2, 2)), co)
