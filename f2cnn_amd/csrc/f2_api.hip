@@ -95,9 +95,12 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     f2_scratch* all[] = {&ctx->coefs, &ctx->offsets, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux,
-                         &ctx->work,  &ctx->work2,   &ctx->tw32,     &ctx->tw64,      &ctx->flags};
+                         &ctx->work,  &ctx->work2,   &ctx->flags};
     for (f2_scratch* s : all)
         if (s->ptr) (void)hipFree(s->ptr);
+    for (auto& prec : ctx->tw)
+        for (f2_scratch& s : prec)
+            if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/f2cnn_hip.h"
@@ -30,8 +31,7 @@ struct f2_ctx {
     f2_scratch stage_aux;
     f2_scratch work;       // intermediates (GFB between K1 and K2, activations, ...)
     f2_scratch work2;
-    f2_scratch tw32, tw64; // FFT twiddle tables
-    int tw32_log2 = -1, tw64_log2 = -1;
+    f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
     std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
     std::vector<double> coefs_host;     // what ctx->coefs currently holds
     f2_scratch flags;      // small device words (error flags)

@@ -1,5 +1,4 @@
 #include "f2_internal.h"
-int f2_launch_envelope(f2_ctx* ctx, const double*, const int64_t*, const int64_t*, int, int, int, double, int, double*) { return f2_fail(ctx, F2_ERR_UNSUPPORTED, "envelope not built yet"); }
 extern "C" {
 int f2_gather_windows(f2_ctx* ctx, const double*, int, int64_t, const int64_t*, int64_t, int, int, int, float*, int) { return f2_fail(ctx, F2_ERR_UNSUPPORTED, "nyi"); }
 int f2_cnn_create(f2_ctx* ctx, const float* const*, int, int, f2_cnn**) { return f2_fail(ctx, F2_ERR_UNSUPPORTED, "nyi"); }

@@ -1,0 +1,105 @@
+"""K2 parity on the GPU, through the C ABI: Hilbert envelope (+LPF) vs the oracle and golden vectors."""
+import numpy as np
+import pytest
+
+import f2cnn_oracle as orc
+from conftest import chan_relerr
+from f2cnn_amd import _lib
+from f2cnn_amd.gammatone import filters
+from f2cnn_amd.scripts.processing import EnvelopeExtraction as EE
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5            # north_star contract, per-channel max-norm
+TOL_F64 = 1e-11       # float64 FFT mode
+
+CASES = ["n1000_c8", "n4096_c8", "n4097_c8", "n16000_c128", "n2500_c128", "impulse_c8", "sine1k_c8",
+         "n1500_f64_c8"]
+
+
+@pytest.mark.parametrize("precision,tol", [(_lib.FFT_F32, TOL), (_lib.FFT_F64, TOL_F64)])
+@pytest.mark.parametrize("tag", CASES)
+def test_golden(golden, tag, precision, tol):
+    gfb = golden[f"g2_{tag}_gfb"]
+    for lpf in (0, 50, 100):
+        key = f"g3_{tag}_env_lpf{lpf}"
+        if key not in golden:
+            continue
+        got = EE.ExtractEnvelopeFromMatrix(gfb, bool(lpf), lpf or 100, precision=precision)
+        assert got.shape == gfb.shape and got.dtype == np.float64
+        err = chan_relerr(got, golden[key])
+        assert err <= tol, (tag, lpf, err)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 64, 100, 255, 256, 257, 511, 513, 1024, 2049,
+                               8192, 8193, 16384])
+def test_all_fft_sizes(N):
+    rng = np.random.default_rng(N)
+    m = rng.standard_normal((3, N)) * np.array([[1.0], [1e-6], [3000.0]])
+    for lpf in (False, True):
+        ref = orc.extract_envelope_from_matrix(m, lpf, 50)
+        assert chan_relerr(EE.ExtractEnvelopeFromMatrix(m, lpf, 50, precision=_lib.FFT_F64), ref) <= TOL_F64
+        assert chan_relerr(EE.ExtractEnvelopeFromMatrix(m, lpf, 50, precision=_lib.FFT_F32), ref) <= TOL
+
+
+def test_fft32_longest_row():
+    m = np.random.default_rng(5).standard_normal((2, 30000))
+    ref = orc.extract_envelope_from_matrix(m, True, 50)
+    assert chan_relerr(EE.ExtractEnvelopeFromMatrix(m, True, 50, precision=_lib.FFT_F32), ref) <= TOL
+
+
+def test_too_long_is_reported_not_wrong():
+    with pytest.raises(_lib.F2Error) as e:
+        EE.ExtractEnvelopeFromMatrix(np.ones((1, 40000)), False, precision=_lib.FFT_F32)
+    assert e.value.code == _lib.F2_ERR_UNSUPPORTED
+
+
+def test_on_filterbank_output_cfg1():
+    # BASELINE config 1: 1 s, 64 channels, LPF 50
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 64, 100))
+    wave = orc.synth_utterance(1234, 16000)
+    gfb = filters.erb_filterbank(wave, coefs)
+    ref = orc.extract_envelope_from_matrix(orc.erb_filterbank(wave, coefs), True, 50)
+    assert chan_relerr(EE.ExtractEnvelopeFromMatrix(gfb, True, 50), ref) <= TOL
+    assert chan_relerr(EE.ExtractEnvelopeFromMatrix(gfb, False), orc.extract_envelope_from_matrix(gfb)) <= TOL
+
+
+def test_ragged_batch():
+    rng = np.random.default_rng(8)
+    mats = [rng.standard_normal((5, n)) for n in (1000, 16000, 3, 4097, 1000)]
+    outs = EE.ExtractEnvelopesFromMatrices(mats, True, 100)
+    for m, o in zip(mats, outs):
+        assert chan_relerr(o, orc.extract_envelope_from_matrix(m, True, 100)) <= TOL
+
+
+def test_in_place_on_device_and_input_untouched():
+    ctx = _lib.default_context()
+    m = np.random.default_rng(9).standard_normal((4, 5000))
+    keep = m.copy()
+    ref = orc.extract_envelope_from_matrix(m, True, 50)
+    d = ctx.malloc(m.nbytes)
+    ctx.h2d(d, m)
+    off = np.array([0, 5000], np.int64)
+    ctx.envelope_batch(d, off, 1, 4, True, 50.0, _lib.FFT_F32, d, _lib.MEM_DEVICE)   # env aliases gfb
+    out = np.empty_like(m)
+    ctx.d2h(out, d)
+    ctx.free(d)
+    assert chan_relerr(out, ref) <= TOL
+    EE.ExtractEnvelopeFromMatrix(m, True, 50)
+    assert np.array_equal(m, keep)
+
+
+def test_properties_full_size():
+    # scaling: env(a*x) = |a| env(x); LPF DC gain 1: constant envelope in, same constant out (late samples)
+    rng = np.random.default_rng(10)
+    m = rng.standard_normal((128, 16000))
+    e1 = EE.ExtractEnvelopeFromMatrix(m, True, 50)
+    e2 = EE.ExtractEnvelopeFromMatrix(-2.5 * m, True, 50)
+    assert chan_relerr(e2, 2.5 * e1) <= 2e-6
+    assert np.all(EE.ExtractEnvelopeFromMatrix(m, False) >= np.abs(m) * (1 - 1e-6))
+
+
+def test_bad_arguments():
+    with pytest.raises(_lib.F2Error):
+        EE.ExtractEnvelopeFromMatrix(np.ones((2, 10)), True, 9000)
+    with pytest.raises(ValueError):
+        EE.ExtractEnvelopeFromMatrix(np.ones(10))
