@@ -15,6 +15,7 @@ F2_OK, F2_ERR_INVALID, F2_ERR_HIP, F2_ERR_UNSUPPORTED, F2_ERR_NOMEM, F2_ERR_NONP
 MEM_HOST, MEM_DEVICE = 0, 1
 WAVE_I16, WAVE_F64 = 0, 1
 FFT_F32, FFT_F64 = 0, 1
+K_COUNT = 5
 
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _P = C.POINTER
@@ -38,6 +39,10 @@ SIGNATURES = {
     "f2_event_destroy": (_i, [_vp, _vp]),
     "f2_event_record": (_i, [_vp, _vp]),
     "f2_event_elapsed_ms": (_i, [_vp, _vp, _vp, _P(C.c_float)]),
+    "f2_prof_enable": (_i, [_vp, _i]),
+    "f2_prof_reset": (_i, [_vp]),
+    "f2_prof_get": (_i, [_vp, _i, _P(_i), _P(C.c_float)]),
+    "f2_prof_kernel_name": (C.c_char_p, [_i]),
     "f2_erb_filterbank_batch": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i]),
     "f2_envelope_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _i, _vp, _i]),
     "f2_filterbank_envelope_fused": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _vp, _i]),
@@ -157,6 +162,22 @@ class Context:
 
     def destroy_event(self, ev):
         self.check(self.lib.f2_event_destroy(self.handle, ev))
+
+    def prof_enable(self, on=True):
+        self.check(self.lib.f2_prof_enable(self.handle, int(on)))
+
+    def prof_get(self):
+        """{kernel name: (launches, total_ms)} since profiling was enabled/reset; waits for the stream."""
+        out = {}
+        for k in range(K_COUNT):
+            n, ms = _i(), C.c_float()
+            self.check(self.lib.f2_prof_get(self.handle, k, C.byref(n), C.byref(ms)))
+            if n.value:
+                out[self.lib.f2_prof_kernel_name(k).decode()] = (n.value, ms.value)
+        return out
+
+    def prof_reset(self):
+        self.check(self.lib.f2_prof_reset(self.handle))
 
     # ---- ops (data pointers: numpy arrays with mem_space HOST, or int device pointers) ----
     def erb_filterbank_batch(self, wave, wave_dtype, offsets, coefs, B, Cn, gfb, mem_space):

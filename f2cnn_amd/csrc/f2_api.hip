@@ -32,6 +32,32 @@ int f2_reserve(f2_ctx* ctx, f2_scratch& s, size_t bytes) {
     return F2_OK;
 }
 
+static int prof_event(f2_ctx* ctx, hipEvent_t* ev) {
+    if (!ctx->prof_pool.empty()) {
+        *ev = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+        return F2_OK;
+    }
+    F2_HIP(ctx, hipEventCreate(ev));
+    return F2_OK;
+}
+
+int f2_prof_begin(f2_ctx* ctx, int kernel_id) {
+    if (!ctx->prof_on) return F2_OK;
+    hipEvent_t a, b;
+    F2_TRY(prof_event(ctx, &a));
+    F2_TRY(prof_event(ctx, &b));
+    ctx->prof[kernel_id].push_back({a, b});
+    F2_HIP(ctx, hipEventRecord(a, ctx->stream));
+    return F2_OK;
+}
+
+int f2_prof_end(f2_ctx* ctx, int kernel_id) {
+    if (!ctx->prof_on) return F2_OK;
+    F2_HIP(ctx, hipEventRecord(ctx->prof[kernel_id].back().second, ctx->stream));
+    return F2_OK;
+}
+
 extern "C" {
 
 int f2_version(void) { return 100; }
@@ -98,6 +124,12 @@ int f2_ctx_destroy(f2_ctx* ctx) {
                          &ctx->work,  &ctx->work2,   &ctx->flags};
     for (f2_scratch* s : all)
         if (s->ptr) (void)hipFree(s->ptr);
+    for (auto& v : ctx->prof)
+        for (auto& pr : v) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     for (auto& prec : ctx->tw)
         for (f2_scratch& s : prec)
             if (s.ptr) (void)hipFree(s.ptr);
@@ -204,6 +236,46 @@ int f2_event_elapsed_ms(f2_ctx* ctx, void* start, void* stop, float* ms) {
     F2_HIP(ctx, hipEventSynchronize((hipEvent_t)stop));
     F2_HIP(ctx, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return F2_OK;
+}
+
+int f2_prof_enable(f2_ctx* ctx, int on) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    ctx->prof_on = on != 0;
+    return on ? f2_prof_reset(ctx) : F2_OK;
+}
+
+int f2_prof_reset(f2_ctx* ctx) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& v : ctx->prof) {
+        for (auto& pr : v) {
+            ctx->prof_pool.push_back(pr.first);
+            ctx->prof_pool.push_back(pr.second);
+        }
+        v.clear();
+    }
+    return F2_OK;
+}
+
+int f2_prof_get(f2_ctx* ctx, int kernel_id, int* launches, float* total_ms) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, kernel_id >= 0 && kernel_id < F2_K_COUNT, F2_ERR_INVALID, "bad kernel id %d", kernel_id);
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float sum = 0.f;
+    for (auto& pr : ctx->prof[kernel_id]) {
+        float ms = 0.f;
+        F2_HIP(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        sum += ms;
+    }
+    if (launches) *launches = (int)ctx->prof[kernel_id].size();
+    if (total_ms) *total_ms = sum;
+    return F2_OK;
+}
+
+const char* f2_prof_kernel_name(int kernel_id) {
+    static const char* names[F2_K_COUNT] = {"k_erb_filterbank", "k_envelope", "k_gather_windows", "k_cnn_forward",
+                                            "k_fused_filterbank_envelope"};
+    return kernel_id >= 0 && kernel_id < F2_K_COUNT ? names[kernel_id] : "";
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -119,8 +119,6 @@ constexpr int plan_shift(int log2h, int pass) {  // log2 of the stride entering 
 // early passes off a single bank)
 __device__ __forceinline__ int cpad(int i) { return i + (i >> 4); }
 constexpr int cpad_size(int h) { return h + (h >> 4) + 1; }
-// padding of the real (envelope) array: one extra slot per chunk of 64
-__device__ __forceinline__ int rpad(int n) { return n + (n >> 6); }
 
 // exp(-2 pi i t / H) from the half-circle table V[k] = exp(-2 pi i k / M), k < H
 template <typename F, int LOG2H>
@@ -201,7 +199,9 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
     constexpr int H = 1 << LOG2H;
     constexpr int M = 2 * H;
     constexpr int CS = cpad_size(H);
-    constexpr int RS = M + (M >> 6) + 1;
+    constexpr int L = M >= NT ? M / NT : 1;   // samples per thread in the low-pass (contiguous chunk)
+    constexpr int TP = NT + 1;                // row pitch of the transposed envelope image
+    constexpr int RS = L * TP;
     constexpr int LDS_BYTES = (CS * 2 > RS ? CS * 2 : RS) * (int)sizeof(F);
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     __shared__ double wave_tot[NT / 64];
@@ -256,23 +256,28 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
     // 4. inverse transform (forward transform of the conjugate)
     fft_all<F, LOG2H>(lds, V, tid);
 
-    // 5. magnitude
+    // 5. magnitude (in F: the FFT already limits the accuracy to F)
     constexpr int PT = (H + NT - 1) / NT;  // packed points per thread
     if (!P.lpf) {
+#pragma unroll 4
         for (int m = tid; m < H; m += NT) {
             const cpx<F> w = lds[cpad(m)];
             const int i0 = 2 * m;
             if (i0 < n) {
-                const double a = x[i0];
-                y[i0] = sqrt(a * a + (double)w.re * (double)w.re);
+                const F a = (F)x[i0];
+                y[i0] = (double)sqrt(a * a + w.re * w.re);
             }
             if (i0 + 1 < n) {
-                const double a = x[i0 + 1];
-                y[i0 + 1] = sqrt(a * a + (double)w.im * (double)w.im);
+                const F a = (F)x[i0 + 1];
+                y[i0 + 1] = (double)sqrt(a * a + w.im * w.im);
             }
         }
         return;
     }
+    // With the low-pass the envelope goes back to LDS, TRANSPOSED: thread t will own the contiguous
+    // samples [t*L, (t+1)*L), so sample n = t*L + j is kept at j*TP + t (TP = 257: conflict-free for
+    // the per-chunk sweeps and for the coalesced copy-out, 2-way on this scatter).
+    auto tpos = [](int i) { return (i % L) * TP + i / L; };
     F e0[PT], e1[PT];
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
@@ -281,14 +286,10 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
         if (m < H) {
             const cpx<F> w = lds[cpad(m)];
             const int i0 = 2 * m;
-            if (i0 < n) {
-                const double a = x[i0];
-                e0[j] = (F)sqrt(a * a + (double)w.re * (double)w.re);
-            }
-            if (i0 + 1 < n) {
-                const double a = x[i0 + 1];
-                e1[j] = (F)sqrt(a * a + (double)w.im * (double)w.im);
-            }
+            const F a = i0 < n ? (F)x[i0] : F(0);
+            const F bb = i0 + 1 < n ? (F)x[i0 + 1] : F(0);
+            e0[j] = sqrt(a * a + w.re * w.re);
+            e1[j] = sqrt(bb * bb + w.im * w.im);
         }
     }
     __syncthreads();
@@ -296,29 +297,24 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
     for (int j = 0; j < PT; ++j) {
         const int m = tid + j * NT;
         if (m < H) {
-            rl[rpad(2 * m)] = e0[j];
-            rl[rpad(2 * m + 1)] = e1[j];
+            rl[tpos(2 * m)] = e0[j];
+            rl[tpos(2 * m + 1)] = e1[j];
         }
     }
     __syncthreads();
 
     // low-pass: chunked recurrence + multiplicative scan over the 256 chunks
-    constexpr int L = M >= NT ? M / NT : 1;
     const int n0 = tid * L;
     const double b0 = P.b0, na1 = -P.a1;
-    const double eprev = (n0 > 0 && n0 <= n) ? (double)rl[rpad(n0 - 1)] : 0.0;
+    const double eprev = (n0 > 0 && n0 <= n) ? (double)rl[tpos(n0 - 1)] : 0.0;
     double yz = 0.0;
     {
         double ep = eprev;
+#pragma unroll 8
         for (int j = 0; j < L; ++j) {
-            const int i = n0 + j;
-            if (i < n) {
-                const double e = (double)rl[rpad(i)];
-                yz = fma(na1, yz, b0 * (e + ep));
-                ep = e;
-            } else {
-                yz = na1 * yz;  // keep the chunk multiplier uniform ((-a1)^L) past the end of the row
-            }
+            const double e = (double)rl[j * TP + tid];   // samples past n hold |0| = 0
+            yz = fma(na1, yz, b0 * (e + ep));
+            ep = e;
         }
     }
     // g = (-a1)^L
@@ -350,18 +346,17 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
     if (lane == 0) yprev = carry;
     {
         double ep = eprev, yy = yprev;
+#pragma unroll 8
         for (int j = 0; j < L; ++j) {
-            const int i = n0 + j;
-            if (i < n) {
-                const double e = (double)rl[rpad(i)];
-                yy = fma(na1, yy, b0 * (e + ep));
-                ep = e;
-                rl[rpad(i)] = (F)yy;
-            }
+            const double e = (double)rl[j * TP + tid];
+            yy = fma(na1, yy, b0 * (e + ep));
+            ep = e;
+            rl[j * TP + tid] = (F)yy;
         }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += NT) y[i] = (double)rl[rpad(i)];
+#pragma unroll 4
+    for (int i = tid; i < n; i += NT) y[i] = (double)rl[tpos(i)];
 }
 
 template <typename F>
@@ -451,6 +446,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         P.ulist = identity ? nullptr : d_lists + pos;
         pos += g.size();
         const dim3 grid((unsigned)(g.size() * (size_t)C)), block(NT);
+        F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
         if (precision == F2_FFT_F32) {
             F2_TRY(ensure_twiddles<float>(ctx, log2h, ctx->tw[0][log2h]));
             const EnvKernel<float> kern = kernel_for<float, MAX_LOG2H_F32>(log2h);
@@ -461,6 +457,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
             hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, P, (const cpx<double>*)ctx->tw[1][log2h].ptr);
         }
         F2_HIP(ctx, hipGetLastError());
+        F2_TRY(f2_prof_end(ctx, F2_K_ENVELOPE));
     }
     return F2_OK;
 }

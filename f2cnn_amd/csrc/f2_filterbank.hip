@@ -94,6 +94,7 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
     (void)h_offsets;
     const int groups = (C + 63) / 64;
     const dim3 grid((unsigned)(B * groups)), block(64);
+    F2_TRY(f2_prof_begin(ctx, F2_K_FILTERBANK));
     if (wave_dtype == F2_WAVE_I16)
         hipLaunchKernelGGL(k_erb_filterbank<int16_t>, grid, block, 0, ctx->stream, (const int16_t*)d_wave, d_offsets,
                            d_coefs, C, groups, d_gfb);
@@ -101,5 +102,6 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
         hipLaunchKernelGGL(k_erb_filterbank<double>, grid, block, 0, ctx->stream, (const double*)d_wave, d_offsets,
                            d_coefs, C, groups, d_gfb);
     F2_HIP(ctx, hipGetLastError());
+    F2_TRY(f2_prof_end(ctx, F2_K_FILTERBANK));
     return F2_OK;
 }

@@ -34,6 +34,9 @@ struct f2_ctx {
     f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
     std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
     std::vector<double> coefs_host;     // what ctx->coefs currently holds
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[F2_K_COUNT];  // (start, stop) per launch
+    std::vector<hipEvent_t> prof_pool;                               // recycled events
     f2_scratch flags;      // small device words (error flags)
     int* host_flags = nullptr;  // pinned mirror
 };
@@ -67,6 +70,10 @@ int f2_reserve(f2_ctx* ctx, f2_scratch& s, size_t bytes);
         int rc_ = (expr);         \
         if (rc_ != F2_OK) return rc_; \
     } while (0)
+
+// RAII-free profiling bracket: F2_PROF_BEGIN before the launch(es) of one kernel id, F2_PROF_END after.
+int f2_prof_begin(f2_ctx* ctx, int kernel_id);
+int f2_prof_end(f2_ctx* ctx, int kernel_id);
 
 static inline int f2_log2_ceil(int64_t n) {
     int k = 0;

@@ -70,6 +70,15 @@ int f2_event_destroy(f2_ctx* ctx, void* event);
 int f2_event_record(f2_ctx* ctx, void* event);                 /* on the context's stream */
 int f2_event_elapsed_ms(f2_ctx* ctx, void* start, void* stop, float* ms); /* waits for `stop` */
 
+/* ---- per-kernel timing (HIP events recorded around every kernel launch on the context's stream) ----
+ * Kernel ids: F2_K_* below. f2_prof_get waits for the stream, returns the number of launches of that
+ * kernel since the last f2_prof_enable(ctx, 1) / f2_prof_reset and their summed device time. */
+enum { F2_K_FILTERBANK = 0, F2_K_ENVELOPE = 1, F2_K_GATHER = 2, F2_K_CNN = 3, F2_K_FUSED = 4, F2_K_COUNT = 5 };
+int f2_prof_enable(f2_ctx* ctx, int on);
+int f2_prof_reset(f2_ctx* ctx);
+int f2_prof_get(f2_ctx* ctx, int kernel_id, int* launches, float* total_ms);
+const char* f2_prof_kernel_name(int kernel_id);
+
 /* ---- K1: ERB gammatone filterbank ------------------------------------------------------------
  * Replaces gammatone/filters.py:195-239 erb_filterbank (called from
  * scripts/processing/GammatoneFiltering.py:42-47 GetFilteredOutputFromArray and
