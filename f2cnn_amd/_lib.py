@@ -198,6 +198,30 @@ class Context:
         self.check(self.lib.f2_gather_windows(self.handle, _ptr(env), Cn, N, _ptr(centers), n_windows, radius, step,
                                               int(bool(normalize)), _ptr(out), mem_space))
 
+    def cnn_create(self, tensors, rows, channels):
+        """tensors: 12 contiguous float32 arrays in Keras layouts (see include/f2cnn_hip.h). Returns a handle."""
+        arrs = [np.ascontiguousarray(t, dtype=np.float32) for t in tensors]
+        if len(arrs) != 12:
+            raise ValueError("the network has 12 weight tensors")
+        ptrs = (_vp * 12)(*[a.ctypes.data for a in arrs])
+        h = _vp()
+        self.check(self.lib.f2_cnn_create(self.handle, ptrs, int(rows), int(channels), C.byref(h)))
+        return h
+
+    def cnn_destroy(self, handle):
+        self.check(self.lib.f2_cnn_destroy(self.handle, handle))
+
+    def cnn_forward(self, handle, x, n, scores, labels, mem_space):
+        self.check(self.lib.f2_cnn_forward(self.handle, handle, _ptr(x), int(n), _ptr(scores), _ptr(labels), mem_space))
+
+    def eval_utterance(self, handle, wave, wave_dtype, N, coefs, Cn, lpf, cutoff, precision, radius, step, env, scores,
+                       labels, mem_space):
+        nb = _i64()
+        self.check(self.lib.f2_eval_utterance(self.handle, handle, _ptr(wave), wave_dtype, int(N), _ptr(coefs), Cn,
+                                              int(bool(lpf)), float(cutoff), precision, radius, step, _ptr(env),
+                                              _ptr(scores), _ptr(labels), C.byref(nb), mem_space))
+        return nb.value
+
 
 _default_ctx = {}
 

@@ -1,0 +1,75 @@
+"""Command line of the hot path, same surface as the reference's f2cnn.py (:68-160) for the commands this
+package implements:
+
+    python -m f2cnn_amd prepare filter
+    python -m f2cnn_amd prepare envelope [--cutoff/-c HZ]
+    python -m f2cnn_amd prepare input [--cutoff HZ] [--label/-l CSV] [--input/-i NPY]
+    python -m f2cnn_amd cnn eval --file/-f WAV [--lpf HZ] [--model/-m NPZ]
+    python -m f2cnn_amd --configure            (writes configF2CNN.conf with the reference's defaults)
+
+organize / label / train / plot need the licensed TIMIT+VTR corpora or Keras and stay with the reference.
+"""
+import argparse
+
+PREPARE = ("filter", "envelope", "input")
+CNN = ("eval",)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(prog="f2cnn_amd", description="F2CNN hot path on MI355X.")
+    parser.add_argument('--configure', action='store_true', help='write configF2CNN.conf with default values')
+    sub = parser.add_subparsers()
+    p = sub.add_parser('prepare', help='data processing commands')
+    p.add_argument('--cutoff', '-c', action='store', dest='CUTOFF', type=int,
+                   help="low pass filter the envelopes with this cutoff frequency")
+    p.add_argument('prepare_command', choices=PREPARE)
+    p.add_argument('--file', '-f', dest='file', nargs='?')
+    p.add_argument('--input', '-i', dest='inputFile', nargs='?')
+    p.add_argument('--label', '-l', dest='labelFile', nargs='?')
+    c = sub.add_parser('cnn', help='CNN commands')
+    c.add_argument('--file', '-f', dest='file', nargs='?')
+    c.add_argument('--model', '-m', dest='model', nargs='?')
+    c.add_argument('cnn_command', choices=CNN)
+    c.add_argument('--lpf', action='store', type=int, dest='CUTOFF', help="low pass filter the envelopes")
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if 'prepare_command' in args:
+        kwargs = {}
+        if args.prepare_command in ('envelope', 'input'):      # f2cnn.py:112-114
+            kwargs['LPF'] = args.CUTOFF is not None
+            kwargs['CUTOFF'] = args.CUTOFF
+        if args.prepare_command == 'input':
+            if args.labelFile is not None:
+                kwargs['labelFile'] = args.labelFile
+            if args.inputFile is not None:
+                kwargs['inputFile'] = args.inputFile
+        if args.prepare_command == 'filter':
+            from .scripts.processing.GammatoneFiltering import FilterAllOrganisedFiles as fn
+        elif args.prepare_command == 'envelope':
+            from .scripts.processing.EnvelopeExtraction import ExtractAllEnvelopes as fn
+        else:
+            from .scripts.processing.InputGenerator import GenerateInputData as fn
+        fn(**kwargs)
+    elif 'cnn_command' in args:
+        if args.file is None:
+            print("Please use --file or -f to give input file")
+            return 1
+        from .scripts.CNN.Evaluating import EvaluateOneWavFile
+        kwargs = {'file': args.file}
+        if args.CUTOFF is not None:                            # f2cnn.py:149-151
+            kwargs['LPF'] = True
+            kwargs['CUTOFF'] = args.CUTOFF
+        if args.model is not None:
+            kwargs['model'] = args.model
+        EvaluateOneWavFile(**kwargs)
+    elif args.configure:
+        from .config import write_default
+        print("Saving configuration file as '{}'".format(write_default()))
+    else:
+        print("No valid command given.")
+        print("For help, use python -m f2cnn_amd --help")
+        return 1
+    return 0

@@ -121,7 +121,7 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     f2_scratch* all[] = {&ctx->coefs, &ctx->offsets, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux,
-                         &ctx->work,  &ctx->work2,   &ctx->flags};
+                         &ctx->work,  &ctx->work2,   &ctx->xbuf,      &ctx->flags};
     for (f2_scratch* s : all)
         if (s->ptr) (void)hipFree(s->ptr);
     for (auto& v : ctx->prof)
@@ -291,7 +291,9 @@ static int check_batch(f2_ctx* ctx, const int64_t* offsets, int B, int C, int me
     return F2_OK;
 }
 
-static int upload_offsets(f2_ctx* ctx, const int64_t* offsets, int B) {
+}  // extern "C" (internal helpers follow)
+
+int f2_upload_offsets(f2_ctx* ctx, const int64_t* offsets, int B) {
     if (ctx->offsets_host.size() == (size_t)(B + 1) &&
         memcmp(ctx->offsets_host.data(), offsets, sizeof(int64_t) * (size_t)(B + 1)) == 0)
         return F2_OK;  // same batch shape as the previous call: the device copy is still valid
@@ -305,7 +307,7 @@ static int upload_offsets(f2_ctx* ctx, const int64_t* offsets, int B) {
     return F2_OK;
 }
 
-static int upload_coefs(f2_ctx* ctx, const double* coefs, int C) {
+int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C) {
     if (ctx->coefs_host.size() == (size_t)C * 10 &&
         memcmp(ctx->coefs_host.data(), coefs, sizeof(double) * 10 * (size_t)C) == 0)
         return F2_OK;
@@ -319,6 +321,8 @@ static int upload_coefs(f2_ctx* ctx, const double* coefs, int C) {
 
 static size_t wave_elem(int wave_dtype) { return wave_dtype == F2_WAVE_I16 ? 2 : 8; }
 
+extern "C" {
+
 int f2_erb_filterbank_batch(f2_ctx* ctx, const void* wave, int wave_dtype, const int64_t* offsets,
                             const double* coefs, int B, int C, double* gfb, int mem_space) {
     F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
@@ -328,8 +332,8 @@ int f2_erb_filterbank_batch(f2_ctx* ctx, const void* wave, int wave_dtype, const
     const int64_t total = offsets[B];
     if (B == 0 || C == 0 || total == 0) return F2_OK;
     F2_CHECK(ctx, wave && coefs && gfb, F2_ERR_INVALID, "null data pointer");
-    F2_TRY(upload_offsets(ctx, offsets, B));
-    F2_TRY(upload_coefs(ctx, coefs, C));
+    F2_TRY(f2_upload_offsets(ctx, offsets, B));
+    F2_TRY(f2_upload_coefs(ctx, coefs, C));
     const void* d_wave = wave;
     double* d_gfb = gfb;
     const size_t out_bytes = sizeof(double) * (size_t)C * (size_t)total;
@@ -360,7 +364,7 @@ int f2_envelope_batch(f2_ctx* ctx, const double* gfb, const int64_t* offsets, in
     const int64_t total = offsets[B];
     if (B == 0 || C == 0 || total == 0) return F2_OK;
     F2_CHECK(ctx, gfb && env, F2_ERR_INVALID, "null data pointer");
-    F2_TRY(upload_offsets(ctx, offsets, B));
+    F2_TRY(f2_upload_offsets(ctx, offsets, B));
     const double* d_gfb = gfb;
     double* d_env = env;
     const size_t bytes = sizeof(double) * (size_t)C * (size_t)total;
@@ -390,8 +394,8 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
     const int64_t total = offsets[B];
     if (B == 0 || C == 0 || total == 0) return F2_OK;
     F2_CHECK(ctx, wave && coefs && env, F2_ERR_INVALID, "null data pointer");
-    F2_TRY(upload_offsets(ctx, offsets, B));
-    F2_TRY(upload_coefs(ctx, coefs, C));
+    F2_TRY(f2_upload_offsets(ctx, offsets, B));
+    F2_TRY(f2_upload_coefs(ctx, coefs, C));
     const size_t bytes = sizeof(double) * (size_t)C * (size_t)total;
     const void* d_wave = wave;
     double* d_env = env;

@@ -1,0 +1,352 @@
+// K4 -- forward pass of the F2CNN network (reference: architecture scripts/CNN/Training.py:93-114,
+// predict + label rule scripts/CNN/Evaluating.py:85-87).
+//
+//   x (n, R, C, 1) -> Conv 3x3 same, 32 + ReLU -> Conv 3x3 valid, 32 + ReLU -> MaxPool 2x2
+//                  -> Conv 3x3 same, 64 + ReLU -> Conv 3x3 valid, 64 + ReLU -> MaxPool 2x2
+//                  -> Flatten (H,W,C order) -> Dense 516 + ReLU -> Dense 2 -> softmax
+//
+// All arithmetic is float32 with float32 accumulation (what Keras/TensorFlow computes). conv2..conv4 and
+// dense1 (98 % of the 21.0 M MAC per window) run as implicit GEMMs on the f32-input matrix cores
+// (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain, so results are deterministic); weights are used in
+// their Keras layouts: a (3,3,Cin,Cout) HWIO kernel flattened is exactly the K x N operand
+// (k = (dy*3+dx)*Cin + ci). Activations are NHWC in HBM between layers, processed in chunks of windows.
+//
+// Implicit-GEMM tile: one wavefront = 2 output rows x 32 output columns x all Cout of one window.
+// Its 4 x 34 x Cin input patch is staged in LDS with a (Cin+1)-float pitch per pixel, so the MFMA A
+// operand (lane = pixel, one k per half-wave) is a conflict-free ds_read_b32; the B operand (lane = Cout)
+// is a coalesced weight row. ReLU, bias and the 2x2 max-pool are applied from the accumulators: the
+// 32x32 accumulator keeps pixel pairs (2t, 2t+1) in one lane, and the second pooled row is the wave's
+// second M-tile, so pooling needs no cross-lane traffic.
+#include "f2_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int C1 = 32, C2 = 32, C3 = 64, C4 = 64, D1 = 516, D2 = 2;
+constexpr int PW = 34;  // patch width: 32 output columns + 2
+
+struct Dims {
+    int H1, W1;        // input / conv1 output
+    int H2, W2;        // conv2 output (valid)
+    int Hp1, Wp1;      // after pool 1 (= conv3 output, same)
+    int H4, W4;        // conv4 output (valid)
+    int Hp2, Wp2;      // after pool 2
+    int flat;
+};
+
+Dims make_dims(int rows, int channels) {
+    Dims d;
+    d.H1 = rows;
+    d.W1 = channels;
+    d.H2 = rows - 2;
+    d.W2 = channels - 2;
+    d.Hp1 = d.H2 / 2;
+    d.Wp1 = d.W2 / 2;
+    d.H4 = d.Hp1 - 2;
+    d.W4 = d.Wp1 - 2;
+    d.Hp2 = d.H4 / 2;
+    d.Wp2 = d.W4 / 2;
+    d.flat = d.Hp2 > 0 && d.Wp2 > 0 ? d.Hp2 * d.Wp2 * C4 : 0;
+    return d;
+}
+
+// ---- conv1: 1 input channel, plain VALU. One thread = one pixel, all 32 output channels. ----
+__global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ x, const float* __restrict__ w,
+                                               const float* __restrict__ bias, float* __restrict__ out, int H, int W,
+                                               int64_t npix) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const int xx = (int)(p % W);
+    const int64_t t = p / W;
+    const int yy = (int)(t % H);
+    const float* img = x + (t - yy) * W;  // start of this window
+    float v[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int y2 = yy + dy - 1, x2 = xx + dx - 1;
+            v[dy * 3 + dx] = (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) ? img[(int64_t)y2 * W + x2] : 0.f;
+        }
+    float* o = out + p * C1;
+#pragma unroll
+    for (int co = 0; co < C1; co += 4) {
+        float4 r;
+        float* rp = &r.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc = fmaf(v[tap], w[tap * C1 + co + q], acc);
+            rp[q] = fmaxf(acc + bias[co + q], 0.f);
+        }
+        *reinterpret_cast<float4*>(o + co) = r;
+    }
+}
+
+// ---- conv2..4: implicit GEMM on v_mfma_f32_32x32x2_f32 ----
+template <int CIN, int COUT, bool SAME, bool POOL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __restrict__ in, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int Hin, int Win, int64_t nwin) {
+    constexpr int PS = CIN + 1;           // LDS pitch per pixel
+    constexpr int PATCH = 4 * PW * PS;    // floats per wave
+    constexpr int NT = COUT / 32;
+    constexpr int PAD = SAME ? 1 : 0;
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* patch = lds_all + wave * PATCH;
+
+    const int Ho = SAME ? Hin : Hin - 2, Wo = SAME ? Win : Win - 2;
+    const int Hout = POOL ? Ho / 2 : Ho, Wout = POOL ? Wo / 2 : Wo;
+    const int row_pairs = POOL ? Ho / 2 : (Ho + 1) / 2;
+    const int wneed = POOL ? (Wo / 2) * 2 : Wo;
+    const int xtiles = (wneed + 31) / 32;
+    const int64_t tasks = nwin * row_pairs * xtiles;
+    int64_t task = (int64_t)blockIdx.x * WAVES + wave;
+    const bool live = task < tasks;
+    if (!live) task = tasks - 1;
+    const int xt = (int)(task % xtiles);
+    const int64_t t2 = task / xtiles;
+    const int rp = (int)(t2 % row_pairs);
+    const int64_t win = t2 / row_pairs;
+    const int y0 = 2 * rp, x0 = 32 * xt;
+
+    // stage the 4 x 34 x CIN patch (zero outside the image: 'same' padding and tile overhang)
+    const float* img = in + win * (int64_t)Hin * Win * CIN;
+    for (int e = lane; e < 4 * PW * CIN; e += 64) {
+        const int r = e / (PW * CIN);
+        const int rem = e - r * (PW * CIN);
+        const int p = rem / CIN, ci = rem - p * CIN;
+        const int yi = y0 - PAD + r, xi = x0 - PAD + p;
+        float v = 0.f;
+        if (yi >= 0 && yi < Hin && xi >= 0 && xi < Win) v = img[((int64_t)yi * Win + xi) * CIN + ci];
+        patch[(r * PW + p) * PS + ci] = v;
+    }
+    __syncthreads();
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[rr][nt][q] = 0.f;
+
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        const float* pa = patch + ((dy * PW) + i + dx) * PS + h;
+        const float* pb = w + ((int64_t)(tap * CIN + h) * COUT) + i;
+#pragma unroll 8
+        for (int ci = 0; ci < CIN; ci += 2) {
+            const float a0 = pa[ci];
+            const float a1 = pa[PW * PS + ci];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float b = pb[(int64_t)ci * COUT + nt * 32];
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    if (!live) return;
+    float* o = out + win * (int64_t)Hout * Wout * COUT;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 32 + i;
+        const float bv = bias[co];
+        if constexpr (POOL) {
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const int px = (x0 + (q & 3) + 8 * (q >> 2) + 4 * h) >> 1;
+                const float m = fmaxf(fmaxf(acc[0][nt][q], acc[0][nt][q + 1]), fmaxf(acc[1][nt][q], acc[1][nt][q + 1]));
+                if (px < Wout) o[((int64_t)rp * Wout + px) * COUT + co] = fmaxf(m + bv, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int y = y0 + rr;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int xo = x0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (y < Ho && xo < Wo) o[((int64_t)y * Wout + xo) * COUT + co] = fmaxf(acc[rr][nt][q] + bv, 0.f);
+                }
+            }
+        }
+    }
+}
+
+// ---- dense1: (n, K) x (K, 516) on the same MFMA; one wave = 32 windows x 32 outputs ----
+__global__ __launch_bounds__(256) void k_dense1_mfma(const float* __restrict__ a, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int K,
+                                                     int64_t n) {
+    constexpr int NTILES = (D1 + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t mtiles = (n + 31) / 32;
+    if (task >= mtiles * NTILES) return;
+    const int nt = (int)(task % NTILES);
+    const int64_t w0 = (task / NTILES) * 32;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t wi = w0 + i < n ? w0 + i : n - 1;
+    const int col = nt * 32 + i;
+    const bool colok = col < D1;
+    const float* pa = a + wi * K + h;
+    const float* pb = w + (int64_t)h * D1 + (colok ? col : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < K; k += 2) {
+        const float av = pa[k];
+        float bv = pb[(int64_t)k * D1];
+        if (!colok) bv = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (!colok) return;
+    const float b = bias[col];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int64_t wr = w0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (wr < n) out[wr * D1 + col] = fmaxf(acc[q] + b, 0.f);
+    }
+}
+
+// ---- dense2 + softmax + label: one thread per window ----
+__global__ __launch_bounds__(256) void k_dense2_softmax(const float* __restrict__ a, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ scores,
+                                                        uint8_t* __restrict__ labels, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* r = a + i * D1;
+    float z0 = 0.f, z1 = 0.f;
+    for (int k = 0; k < D1; ++k) {
+        const float v = r[k];
+        z0 = fmaf(v, w[2 * k], z0);
+        z1 = fmaf(v, w[2 * k + 1], z1);
+    }
+    z0 += bias[0];
+    z1 += bias[1];
+    const float m = fmaxf(z0, z1);
+    const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+    const float s = e0 + e1;
+    const float s0 = e0 / s, s1 = e1 / s;
+    if (scores) {
+        scores[2 * i] = s0;
+        scores[2 * i + 1] = s1;
+    }
+    if (labels) labels[i] = s1 > s0 ? 1 : 0;   // ties -> 0 ("falling"), Evaluating.py:87
+}
+
+template <int CIN, int COUT, bool SAME, bool POOL, int WAVES>
+int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, float* out, int Hin, int Win, int64_t n) {
+    const int Ho = SAME ? Hin : Hin - 2, Wo = SAME ? Win : Win - 2;
+    const int row_pairs = POOL ? Ho / 2 : (Ho + 1) / 2;
+    const int wneed = POOL ? (Wo / 2) * 2 : Wo;
+    const int xtiles = (wneed + 31) / 32;
+    const int64_t tasks = n * row_pairs * xtiles;
+    if (tasks <= 0) return F2_OK;
+    constexpr size_t lds = sizeof(float) * WAVES * 4 * PW * (CIN + 1);
+    auto kern = k_conv3x3_mfma<CIN, COUT, SAME, POOL, WAVES>;
+    if (lds > 64 * 1024)
+        F2_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t blocks = (tasks + WAVES - 1) / WAVES;
+    F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, ctx->stream, in, w, b, out, Hin, Win, n);
+    F2_HIP(ctx, hipGetLastError());
+    return F2_OK;
+}
+
+}  // namespace
+
+size_t f2_cnn_workspace_floats(const f2_cnn* cnn) {
+    const Dims d = make_dims(cnn->rows, cnn->channels);
+    return (size_t)d.H1 * d.W1 * C1 + (size_t)d.Hp1 * d.Wp1 * C2 + (size_t)d.Hp1 * d.Wp1 * C3 + (size_t)d.flat + D1;
+}
+
+int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_ws, float* d_scores,
+                  uint8_t* d_labels) {
+    if (n <= 0) return F2_OK;
+    const Dims d = make_dims(cnn->rows, cnn->channels);
+    float* a1 = d_ws;
+    float* a2 = a1 + (size_t)n * d.H1 * d.W1 * C1;
+    float* a3 = a2 + (size_t)n * d.Hp1 * d.Wp1 * C2;
+    float* a4 = a3 + (size_t)n * d.Hp1 * d.Wp1 * C3;
+    float* a5 = a4 + (size_t)n * d.flat;
+    F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
+    const int64_t npix = n * d.H1 * d.W1;
+    hipLaunchKernelGGL(k_conv1, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, d_x, cnn->t(0), cnn->t(1),
+                       a1, d.H1, d.W1, npix);
+    F2_HIP(ctx, hipGetLastError());
+    F2_TRY((launch_conv<C1, C2, false, true, 4>(ctx, a1, cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n)));
+    F2_TRY((launch_conv<C2, C3, true, false, 4>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
+    F2_TRY((launch_conv<C3, C4, false, true, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
+    {
+        const int64_t tasks = ((n + 31) / 32) * ((D1 + 31) / 32);
+        hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, ctx->stream, a4, cnn->t(8),
+                           cnn->t(9), a5, d.flat, n);
+        F2_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_dense2_softmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a5, cnn->t(10),
+                       cnn->t(11), d_scores, d_labels, n);
+    F2_HIP(ctx, hipGetLastError());
+    F2_TRY(f2_prof_end(ctx, F2_K_CNN));
+    return F2_OK;
+}
+
+extern "C" {
+
+int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channels, f2_cnn** out) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, tensors && out, F2_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const Dims d = make_dims(rows, channels);
+    F2_CHECK(ctx, rows >= 3 && channels >= 3 && d.flat > 0, F2_ERR_INVALID,
+             "input of %d x %d is too small for the network (needs a non-empty flatten)", rows, channels);
+    const size_t sizes[12] = {9 * C1, C1, 9 * (size_t)C1 * C2, C2, 9 * (size_t)C2 * C3, C3, 9 * (size_t)C3 * C4, C4,
+                              (size_t)d.flat * D1, D1, (size_t)D1 * D2, D2};
+    for (int i = 0; i < 12; ++i) F2_CHECK(ctx, tensors[i], F2_ERR_INVALID, "weight tensor %d is NULL", i);
+    F2_HIP(ctx, hipSetDevice(ctx->device));
+    f2_cnn* cnn = new f2_cnn();
+    cnn->rows = rows;
+    cnn->channels = channels;
+    cnn->flat = d.flat;
+    cnn->dev = ctx->device;
+    size_t total = 0;
+    for (int i = 0; i < 12; ++i) {
+        cnn->off[i] = total;
+        total += (sizes[i] + 63) & ~size_t(63);   // keep every tensor 256-byte aligned
+    }
+    hipError_t e = hipMalloc((void**)&cnn->blob, total * sizeof(float));
+    if (e != hipSuccess) {
+        delete cnn;
+        return f2_fail(ctx, F2_ERR_NOMEM, "hipMalloc(%zu) -> %s", total * sizeof(float), hipGetErrorString(e));
+    }
+    for (int i = 0; i < 12; ++i) {
+        e = hipMemcpyAsync(cnn->blob + cnn->off[i], tensors[i], sizes[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) break;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(cnn->blob);
+        delete cnn;
+        return f2_fail(ctx, F2_ERR_HIP, "uploading CNN weights -> %s", hipGetErrorString(e));
+    }
+    *out = cnn;
+    return F2_OK;
+}
+
+int f2_cnn_destroy(f2_ctx* ctx, f2_cnn* cnn) {
+    if (!cnn) return F2_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (cnn->blob) (void)hipFree(cnn->blob);
+    delete cnn;
+    return F2_OK;
+}
+
+}  // extern "C"

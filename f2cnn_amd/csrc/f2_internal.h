@@ -31,6 +31,7 @@ struct f2_ctx {
     f2_scratch stage_aux;
     f2_scratch work;       // intermediates (GFB between K1 and K2, activations, ...)
     f2_scratch work2;
+    f2_scratch xbuf;       // window tensor chunk between K3 and K4
     f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
     std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
     std::vector<double> coefs_host;     // what ctx->coefs currently holds
@@ -43,14 +44,21 @@ struct f2_ctx {
 
 struct f2_cnn {
     int rows = 0, channels = 0, flat = 0;
+    int dev = 0;
     float* blob = nullptr;       // all tensors, device
     size_t off[12] = {0};        // element offsets of the 12 tensors in `blob`
+    const float* t(int i) const { return blob + off[i]; }
 };
+
+// activation workspace (floats) the CNN needs per window
+size_t f2_cnn_workspace_floats(const f2_cnn* cnn);
 
 extern char g_f2_err[512];
 
 int f2_fail(f2_ctx* ctx, int code, const char* fmt, ...);
 int f2_reserve(f2_ctx* ctx, f2_scratch& s, size_t bytes);
+int f2_upload_offsets(f2_ctx* ctx, const int64_t* offsets, int B);
+int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C);
 
 #define F2_HIP(ctx, call)                                                                      \
     do {                                                                                       \
@@ -86,7 +94,9 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
                          const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb);
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
                        int B, int C, int lpf, double cutoff_hz, int precision, double* d_env);
+// d_centers == NULL: window e is centred at first_center + e
 int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const int64_t* d_centers,
-                     int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag);
-int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_scores,
+                     int64_t first_center, int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag);
+// runs the network on n windows (n <= chunk the workspace was sized for); d_ws: n * workspace floats
+int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_ws, float* d_scores,
                   uint8_t* d_labels);

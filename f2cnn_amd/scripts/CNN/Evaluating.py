@@ -1,0 +1,70 @@
+"""Drop-in for the hot-path part of the reference's ``scripts/CNN/Evaluating.py``: WAV -> filterbank ->
+envelope -> every-sample 11xC windows -> normalise -> CNN -> rising/falling label per sample
+(``EvaluateOneWavArray`` :42-87, ``EvaluateOneWavFile`` :116-135). Accuracy against VTR labels and the
+plots (:89-113) need the TIMIT/VTR side files and are outside this path; the scores and labels are
+returned and saved next to the WAV instead."""
+import os
+
+import numpy
+
+from ... import _lib
+from ...config import F2Config
+from ...gammatone import filters
+from ...model import F2CNNModel, load_model
+from ..processing.EnvelopeExtraction import FFT_PRECISION
+from ..processing.GammatoneFiltering import GetArrayFromWAV
+
+
+def EvaluateOneWavArray(wavArray, framerate, wavFileName=None, model='last_trained_model', LPF=False, CUTOFF=100,
+                        CENTER_FREQUENCIES=None, FILTERBANK_COEFFICIENTS=None, ctx=None, return_envelopes=False):
+    """Returns (scores (nb,2) float32, labels (nb,) uint8 [, envelopes (C,N) float64]); nb = N - 11*STEP."""
+    ctx = ctx or _lib.default_context()
+    cfg = F2Config()
+    if FILTERBANK_COEFFICIENTS is None:
+        CENTER_FREQUENCIES = filters.centre_freqs(framerate, cfg.nchannels, cfg.low_freq)
+        FILTERBANK_COEFFICIENTS = filters.make_erb_filters(framerate, CENTER_FREQUENCIES)
+    coefs = numpy.ascontiguousarray(FILTERBANK_COEFFICIENTS, dtype=numpy.float64)
+    Cn = coefs.shape[0]
+    if not isinstance(model, F2CNNModel):
+        model = load_model(model)
+    print("Applying filterbank...")
+    if not LPF:
+        print("Extracting Envelope...")
+    else:
+        print("Extraction Envelope with {}Hz Low Pass Filter...".format(CUTOFF))
+    wave, dt = filters._wave_args(wavArray)
+    N = wave.shape[0]
+    STEP = int(framerate * cfg.sampling_period * (1 / 1000000.))
+    nb = max(int(N - cfg.dots_per_input * STEP), 0)
+    print("Generating input data for CNN...")
+    print("INPUT SHAPE:", (nb, cfg.dots_per_input, Cn))
+    scores = numpy.empty((nb, 2), numpy.float32)
+    labels = numpy.empty(nb, numpy.uint8)
+    env = numpy.empty((Cn, N), numpy.float64) if return_envelopes else None
+    print("Evaluating the data with the pretrained model...")
+    try:
+        got = ctx.eval_utterance(model.handle(ctx), wave, dt, N, coefs, Cn, bool(LPF), CUTOFF if LPF else 0.0,
+                                 FFT_PRECISION, cfg.radius, STEP, env, scores, labels, _lib.MEM_HOST)
+    except _lib.F2Error as e:
+        if e.code == _lib.F2_ERR_NONPOSITIVE:
+            raise ValueError("values must all be positive")
+        raise
+    assert got == nb
+    return (scores, labels, env) if return_envelopes else (scores, labels)
+
+
+def EvaluateOneWavFile(file, LPF=False, CUTOFF=50, model='last_trained_model', CENTER_FREQUENCIES=None,
+                       FILTERBANK_COEFFICIENTS=None):
+    """`cnn eval --file X.WAV`: writes <base>.F2CNN.npz (scores, labels) and returns (scores, labels)."""
+    print('Using model', model if not isinstance(model, F2CNNModel) else '<in-memory model>')
+    print("File:\t\t{}".format(file))
+    framerate, wavArray = GetArrayFromWAV(file)
+    scores, labels = EvaluateOneWavArray(wavArray, framerate, file, model=model, LPF=LPF, CUTOFF=CUTOFF,
+                                         CENTER_FREQUENCIES=CENTER_FREQUENCIES,
+                                         FILTERBANK_COEFFICIENTS=FILTERBANK_COEFFICIENTS)
+    out = os.path.splitext(file)[0] + '.F2CNN.npz'
+    numpy.savez(out, scores=scores, labels=labels)
+    rising = int(labels.sum())
+    print("\t\t{}\tdone ! {} windows: {} rising, {} falling -> {}".format(file, len(labels), rising,
+                                                                          len(labels) - rising, out))
+    return scores, labels

@@ -1,0 +1,84 @@
+"""Drop-in for the reference's ``scripts/processing/GammatoneFiltering.py``: WAV -> gammatone filterbank
+-> ``<base>.GFB.npy`` (NPY v1.0, '<f8', C-order (C,N), row 0 = highest centre frequency).
+
+The per-file process pool of the reference (:122-125) becomes batches of files per GPU launch; with several
+ranks (torchrun or F2CNN_RANK/F2CNN_WORLD) rank r handles files[r::world] of the sorted list.
+"""
+import glob
+import os
+import time
+
+import numpy
+
+from ...config import F2Config
+from ...gammatone import filters
+from ...runtime import shard_for_rank
+from ...wavio import read_audio
+
+
+def GetArrayFromWAV(filename):
+    """(framerate, samples) of a RIFF or NIST SPHERE file (reference :28-39)."""
+    return read_audio(filename)
+
+
+def GetFilteredOutputFromArray(array, FILTERBANK_COEFFICIENTS):
+    return filters.erb_filterbank(array, FILTERBANK_COEFFICIENTS)
+
+
+def GetFilteredOutputFromFile(filename, FILTERBANK_COEFFICIENTS):
+    framerate, wavArray = GetArrayFromWAV(filename)
+    return GetFilteredOutputFromArray(wavArray, FILTERBANK_COEFFICIENTS), framerate
+
+
+def saveGFBMatrix(filename, matrix):
+    numpy.save(filename, matrix)
+
+
+def loadGFBMatrix(filename):
+    return numpy.load(filename + '.npy')
+
+
+def GammatoneFiltering(wavFile, FILTERBANK_COEFFICIENTS, n=None, done=None):
+    gfbFilename = os.path.splitext(wavFile)[0] + '.GFB'
+    print("Filtering:\t{}".format(wavFile))
+    outputMatrix, _ = GetFilteredOutputFromFile(wavFile, FILTERBANK_COEFFICIENTS)
+    print("Saving:\t\t{}.npy".format(gfbFilename))
+    saveGFBMatrix(gfbFilename, outputMatrix)
+    if n is not None:
+        print("\t\t{:<50} done ! {}/{} Files.".format(wavFile, done, n))
+
+
+def filterbank_from_config(cfg=None):
+    cfg = cfg or F2Config()
+    cf = filters.centre_freqs(cfg.framerate, cfg.nchannels, cfg.low_freq)
+    return cf, filters.make_erb_filters(cfg.framerate, cf)
+
+
+def FilterAllOrganisedFiles(batch_files=32):
+    """`prepare filter`: every resources/f2cnn/*/*.WAV -> .GFB.npy (reference :93-128)."""
+    TotalTime = time.time()
+    wavFiles = sorted(glob.glob(os.path.join("resources", "f2cnn", "*", "*.WAV")))
+    if not wavFiles:
+        print("NO WAV FILES FOUND, PLEASE ORGANIZE FILES")
+        exit(-1)
+    print("\n###############################\nApplying FilterBank to files in '{}'.".format(
+        os.path.split(wavFiles[0])[0]))
+    print(len(wavFiles), "files found")
+    _, coefs = filterbank_from_config()
+    mine = shard_for_rank(wavFiles)
+    done = 0
+    for s in range(0, len(mine), batch_files):
+        names = mine[s:s + batch_files]
+        waves = []
+        for name in names:
+            print("Filtering:\t{}".format(name))
+            waves.append(GetArrayFromWAV(name)[1])
+        for name, m in zip(names, filters.erb_filterbank_batch(waves, coefs)):
+            gfb = os.path.splitext(name)[0] + '.GFB'
+            print("Saving:\t\t{}.npy".format(gfb))
+            saveGFBMatrix(gfb, m)
+            done += 1
+            print("\t\t{:<50} done ! {}/{} Files.".format(name, done, len(mine)))
+    print("Filtered and Saved all files.")
+    print('                Total time:', time.time() - TotalTime)
+    print('')

@@ -1,0 +1,140 @@
+"""K3 (window gather + normalise), K4 (CNN forward) and the `cnn eval` pipeline on the GPU, through the C ABI."""
+import numpy as np
+import pytest
+
+import f2cnn_oracle as orc
+from conftest import chan_relerr
+from f2cnn_amd import _lib
+from f2cnn_amd.gammatone import filters
+from f2cnn_amd.model import F2CNNModel
+from f2cnn_amd.scripts.CNN import Evaluating
+from f2cnn_amd.scripts.CNN.Training import normalizeInput
+from f2cnn_amd.scripts.processing import InputGenerator
+from test_oracle_golden import g4_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_weights(m):
+    return dict(m.tensors)
+
+
+def test_gather_matches_reference_golden(golden):
+    envs, per_file = g4_inputs(golden)
+    blocks = [InputGenerator.gather_windows(envs[k], per_file[k], 5, 160) for k in sorted(per_file)]
+    got = np.concatenate(blocks)
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got, golden["g4_input_data"])      # pure gather: bit exact
+
+
+def test_gather_edges_and_errors():
+    env = np.random.default_rng(0).random((7, 2000)) + 0.1
+    w = InputGenerator.gather_windows(env, [800, 1199], 5, 160)
+    np.testing.assert_array_equal(w, orc.gather_windows(env, [800, 1199]).astype(np.float32))
+    for bad in (799, 1200, -5):
+        with pytest.raises(_lib.F2Error) as e:
+            InputGenerator.gather_windows(env, [bad], 5, 160)
+        assert e.value.code == _lib.F2_ERR_INVALID
+    assert InputGenerator.gather_windows(env, [], 5, 160).shape == (0, 11, 7)
+    # other geometry
+    w = InputGenerator.gather_windows(env, [30, 100], 2, 7)
+    np.testing.assert_array_equal(w, orc.gather_windows(env, [30, 100], 2, 7).astype(np.float32))
+
+
+def test_normalize_input_golden(golden):
+    got = normalizeInput(golden["g6_in_f64"])
+    assert got.dtype == np.float64 and got.shape == (11, 128)
+    np.testing.assert_allclose(got, golden["g6_out_f64"], atol=1e-7)     # float32 result of a float64 computation
+    got32 = normalizeInput(golden["g6_in_f32"])
+    assert got32.dtype == np.float32 and got32.shape == (11, 128, 1)
+    np.testing.assert_allclose(got32, golden["g6_out_f32"], atol=3e-7)
+    np.testing.assert_array_equal(normalizeInput(np.full((11, 128), 3.25)), golden["g6_const_out"])
+    with pytest.raises(ValueError):
+        normalizeInput(np.zeros((11, 128)))
+    bad = golden["g6_in_f64"].copy()
+    bad[3, 5] = -1.0
+    with pytest.raises(ValueError):
+        normalizeInput(bad)
+
+
+def test_eval_windows_normalised():
+    ctx = _lib.default_context()
+    env = np.random.default_rng(2).random((128, 3000)) * 40 + 1e-3
+    nb = 3000 - 1760
+    out = np.empty((nb, 11, 128), np.float32)
+    ctx.gather_windows(env, 128, 3000, None, nb, 5, 160, True, out, _lib.MEM_HOST)
+    ref = orc.eval_input_tensor(env)[..., 0]
+    np.testing.assert_allclose(out, ref, atol=2e-7)
+    assert out.min() == 0.0 and out.max() == 1.0
+
+
+@pytest.mark.parametrize("rows,channels,n", [(11, 128, 257), (11, 64, 40), (13, 40, 33)])
+def test_cnn_forward_vs_oracle(rows, channels, n):
+    m = F2CNNModel.glorot(7, rows, channels, zero_bias=False)
+    x = np.random.default_rng(3).random((n, rows, channels)).astype(np.float32)
+    scores, labels = m.predict_labels(x)
+    ref = orc.cnn_forward(x, oracle_weights(m))
+    assert scores.shape == (n, 2) and scores.dtype == np.float32
+    np.testing.assert_allclose(scores, ref, atol=2e-5)
+    ref_labels = orc.labels_from_scores(ref)
+    decided = np.abs(ref[:, 1] - ref[:, 0]) > 1e-4
+    assert decided.mean() > 0.9
+    np.testing.assert_array_equal(labels[decided], ref_labels[decided])
+    np.testing.assert_array_equal(labels, (scores[:, 1] > scores[:, 0]).astype(np.uint8))
+    np.testing.assert_array_equal(m.predict(x[..., None]), scores)       # (n,R,C,1) accepted like Keras
+
+
+def test_cnn_structured_inputs():
+    # a shifted impulse probes every tap / padding edge of the conv stack; zeros probe the biases
+    m = F2CNNModel.glorot(11, zero_bias=False)
+    x = np.zeros((24, 11, 128), np.float32)
+    for i in range(1, 24):
+        x[i, (i * 5) % 11, (i * 37) % 128] = 1.0 + i
+    np.testing.assert_allclose(m.predict(x), orc.cnn_forward(x, oracle_weights(m)), atol=2e-5)
+
+
+def test_cnn_chunking_is_invisible():
+    m = F2CNNModel.glorot(5)
+    x = np.random.default_rng(4).random((4096 + 70, 11, 128)).astype(np.float32)
+    s = m.predict(x)
+    np.testing.assert_array_equal(s[:64], m.predict(x[:64]))
+    np.testing.assert_array_equal(s[-70:], m.predict(x[-70:]))
+
+
+def test_torch_state_dict_conversion():
+    import torch
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({
+        "conv1": torch.nn.Conv2d(1, 32, 3, padding=1), "conv2": torch.nn.Conv2d(32, 32, 3),
+        "conv3": torch.nn.Conv2d(32, 64, 3, padding=1), "conv4": torch.nn.Conv2d(64, 64, 3),
+        "dense1": torch.nn.Linear(1920, 516), "dense2": torch.nn.Linear(516, 2)})
+    x = torch.rand(9, 1, 11, 128)
+    with torch.no_grad():
+        h = torch.relu(net["conv2"](torch.relu(net["conv1"](x))))
+        h = torch.nn.functional.max_pool2d(h, 2)
+        h = torch.relu(net["conv4"](torch.relu(net["conv3"](h))))
+        h = torch.nn.functional.max_pool2d(h, 2).flatten(1)
+        ref = torch.softmax(net["dense2"](torch.relu(net["dense1"](h))), dim=1).numpy()
+    m = F2CNNModel.from_torch_state_dict(net.state_dict())
+    np.testing.assert_allclose(m.predict(x[:, 0].numpy()), ref, atol=2e-5)
+    np.testing.assert_allclose(orc.cnn_forward(x[:, 0].numpy(), oracle_weights(m)), ref, atol=2e-5)
+
+
+def test_eval_pipeline_cfg4_shape(tmp_path, monkeypatch):
+    # BASELINE config 4 in miniature: one 0.25 s utterance end to end, labels vs the oracle chain
+    monkeypatch.chdir(tmp_path)
+    wave = orc.synth_utterance(2028, 4000)
+    m = F2CNNModel.glorot(7)
+    scores, labels, env = Evaluating.EvaluateOneWavArray(wave, 16000, model=m, LPF=True, CUTOFF=50, return_envelopes=True)
+    nb = 4000 - 1760
+    assert scores.shape == (nb, 2) and labels.shape == (nb,)
+    coefs = orc.make_erb_filters(16000, orc.centre_freqs(16000, 128, 100))
+    env_ref = orc.filter_and_envelope(wave, coefs, True, 50)
+    assert chan_relerr(env, env_ref) <= 1e-5
+    ref = orc.cnn_forward(orc.eval_input_tensor(env_ref), oracle_weights(m))
+    np.testing.assert_allclose(scores, ref, atol=5e-4)
+    decided = np.abs(ref[:, 1] - ref[:, 0]) > 2e-3
+    np.testing.assert_array_equal(labels[decided], orc.labels_from_scores(ref)[decided])
+    # too short for a single window: no scores, no error
+    s2, l2 = Evaluating.EvaluateOneWavArray(wave[:1700], 16000, model=m)
+    assert s2.shape == (0, 2) and l2.shape == (0,)
