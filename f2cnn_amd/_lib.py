@@ -227,9 +227,9 @@ _default_ctx = {}
 
 
 def default_context(device=None):
-    """Process-wide context per device (device defaults to $F2CNN_DEVICE or 0)."""
+    """Process-wide context per device (default: $F2CNN_DEVICE, else torchrun's $LOCAL_RANK, else 0)."""
     if device is None:
-        device = int(os.environ.get("F2CNN_DEVICE", "0"))
+        device = int(os.environ.get("F2CNN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     ctx = _default_ctx.get(device)
     if ctx is None or ctx.handle is None:
         ctx = _default_ctx[device] = Context(device)

@@ -1,0 +1,73 @@
+"""The file-level drop-in on the GPU: `prepare filter` -> `prepare envelope` -> `prepare input` -> `cnn eval`
+through the CLI, with the reference's directory layout, file names and .npy formats."""
+import os
+
+import numpy as np
+import pytest
+
+import f2cnn_oracle as orc
+from conftest import chan_relerr
+from f2cnn_amd import cli, config, wavio
+from f2cnn_amd.model import F2CNNModel
+
+pytestmark = pytest.mark.gpu
+
+
+def npy_header(path):
+    with open(path, "rb") as f:
+        assert f.read(6) == b"\x93NUMPY"
+        major, minor = f.read(1)[0], f.read(1)[0]
+        hlen = int.from_bytes(f.read(2), "little")
+        return (major, minor), f.read(hlen).decode()
+
+
+def test_prepare_and_eval_cli(tmp_path, monkeypatch, capsys):
+    from scipy.io import wavfile
+    monkeypatch.chdir(tmp_path)
+    config.write_default()
+    lens = {"TEST/DR1.FAAA0.SA1": 4000, "TEST/DR1.FBBB0.SX2": 2500, "TRAIN/DR2.MCCC0.SI3": 4097}
+    waves = {}
+    for i, (key, n) in enumerate(lens.items()):
+        os.makedirs(os.path.join("resources", "f2cnn", os.path.dirname(key)), exist_ok=True)
+        waves[key] = orc.synth_utterance(100 + i, n)
+        path = os.path.join("resources", "f2cnn", key + ".WAV")
+        if i == 1:
+            wavfile.write(path, 16000, waves[key])        # RIFF
+        else:
+            wavio.write_sphere(path, 16000, waves[key])   # NIST SPHERE, like TIMIT
+    assert cli.main(["prepare", "filter"]) == 0
+    assert cli.main(["prepare", "envelope", "--cutoff", "50"]) == 0
+    coefs = orc.make_erb_filters(16000, orc.centre_freqs(16000, 128, 100))
+    for key, n in lens.items():
+        base = os.path.join("resources", "f2cnn", key)
+        ver, hdr = npy_header(base + ".GFB.npy")
+        assert ver == (1, 0) and "'<f8'" in hdr and "False" in hdr and f"(128, {n})" in hdr
+        gfb, env = np.load(base + ".GFB.npy"), np.load(base + ".ENV1.npy")
+        assert env.shape == (128, n) and env.dtype == np.float64
+        ref = orc.erb_filterbank(waves[key], coefs)
+        assert chan_relerr(gfb, ref) <= 1e-10
+        assert chan_relerr(env, orc.extract_envelope_from_matrix(ref, True, 50)) <= 1e-5
+    # prepare input
+    os.makedirs("trainingData")
+    rows = [("TRAIN", "DR2", "MCCC0", "SI3", "aa", 900), ("TEST", "DR1", "FAAA0", "SA1", "iy", 800),
+            ("TEST", "DR1", "FBBB0", "SX2", "eh", 1600), ("TEST", "DR1", "FAAA0", "SA1", "ae", 3199)]
+    with open("trainingData/label_data.csv", "w") as f:
+        for r in rows:
+            f.write(",".join(map(str, r)) + ",0.5,0.01,1\n")
+    assert cli.main(["prepare", "input", "--cutoff", "50"]) == 0
+    x = np.load("trainingData/input_data_LPF50.npy")
+    assert x.shape == (4, 11, 128) and x.dtype == np.float32
+    np.testing.assert_array_equal(x, np.load("trainingData/last_input_data.npy"))
+    order = [("TEST/DR1.FAAA0.SA1", 800), ("TEST/DR1.FAAA0.SA1", 3199), ("TEST/DR1.FBBB0.SX2", 1600),
+             ("TRAIN/DR2.MCCC0.SI3", 900)]                      # sorted(file), CSV order inside a file
+    for e, (key, tp) in enumerate(order):
+        env = np.load(os.path.join("resources", "f2cnn", key + ".ENV1.npy"))
+        np.testing.assert_array_equal(x[e], orc.gather_windows(env, [tp])[0].astype(np.float32))
+    # cnn eval
+    F2CNNModel.glorot(7).save("last_trained_model.npz")
+    wav = os.path.join("resources", "f2cnn", "TEST", "DR1.FAAA0.SA1.WAV")
+    assert cli.main(["cnn", "eval", "--file", wav, "--lpf", "50", "--model", "last_trained_model.npz"]) == 0
+    res = np.load(os.path.join("resources", "f2cnn", "TEST", "DR1.FAAA0.SA1.F2CNN.npz"))
+    assert res["scores"].shape == (4000 - 1760, 2) and res["labels"].shape == (4000 - 1760,)
+    out = capsys.readouterr().out
+    assert "Total time:" in out and "done !" in out

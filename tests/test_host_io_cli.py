@@ -1,0 +1,105 @@
+"""CPU-only tests of the host side: audio readers, config, CSV parsing, model container, CLI parsing, sharding."""
+import os
+
+import numpy as np
+import pytest
+
+from f2cnn_amd import cli, config, model, runtime, wavio
+from f2cnn_amd.scripts.processing import EnvelopeExtraction, InputGenerator
+
+
+def test_sphere_and_riff_roundtrip(tmp_path):
+    from scipy.io import wavfile
+    x = (np.random.default_rng(0).standard_normal(1234) * 3000).astype(np.int16)
+    sph, riff = tmp_path / "a.WAV", tmp_path / "b.WAV"
+    wavio.write_sphere(sph, 16000, x)
+    wavfile.write(riff, 16000, x)
+    for p in (sph, riff):
+        rate, y = wavio.read_audio(p)
+        assert rate == 16000 and y.dtype == np.int16
+        np.testing.assert_array_equal(x, y)
+    # big-endian SPHERE body
+    raw = open(sph, "rb").read()
+    be = raw[:1024].replace(b"sample_byte_format -s2 01", b"sample_byte_format -s2 10") + x.astype(">i2").tobytes()
+    p = tmp_path / "c.WAV"
+    p.write_bytes(be)
+    np.testing.assert_array_equal(wavio.read_audio(p)[1], x)
+    (tmp_path / "d.WAV").write_bytes(b"JUNKJUNKJUNKJUNKJUNK")
+    with pytest.raises(ValueError):
+        wavio.read_audio(tmp_path / "d.WAV")
+
+
+def test_config_defaults_and_file(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    c = config.F2Config()
+    assert not c.found and (c.framerate, c.nchannels, c.low_freq, c.radius) == (16000, 128, 100, 5)
+    assert c.dots_per_input == 11 and c.step == 160
+    config.write_default(nchannels=64, radius=3)
+    c = config.F2Config()
+    assert c.found and c.nchannels == 64 and c.dots_per_input == 7
+    # the file is readable the way the reference reads it (ConfigParser lower-cases keys)
+    from configparser import ConfigParser
+    cp = ConfigParser()
+    cp.read("configF2CNN.conf")
+    assert cp.getint("FILTERBANK", "NCHANNELS") == 64 and cp.getint("CNN", "SAMPLING_PERIOD") == 10000
+
+
+def test_label_csv_parsing(tmp_path):
+    p = tmp_path / "l.csv"
+    p.write_text("TRAIN,DR2,MABC0,SX10,aa,8000,0.5,0.01,1\nTEST,DR1,FXYZ0,SA1,iy,800,0.5,0.01,0\n"
+                 "TRAIN,DR2,MABC0,SX10,eh,960,0.5,0.01,1\n")
+    d = InputGenerator.GetListOfEnvelopeFilesAndTimepoints(str(p))
+    assert d == {os.path.join("TRAIN", "DR2.MABC0.SX10.ENV1.npy"): [8000, 960],
+                 os.path.join("TEST", "DR1.FXYZ0.SA1.ENV1.npy"): [800]}
+
+
+def test_envelope_filename():
+    assert EnvelopeExtraction.envelope_filename("resources/f2cnn/TEST/DR1.X.SA1.GFB.npy") == "resources/f2cnn/TEST/DR1.X.SA1.ENV1"
+
+
+def test_model_container(tmp_path):
+    m = model.F2CNNModel.glorot(7)
+    assert sum(t.size for t in m.tensors.values()) == 1057262
+    assert [t.shape for t in m.ordered()][:4] == [(3, 3, 1, 32), (32,), (3, 3, 32, 32), (32,)]
+    m.save(tmp_path / "w.npz")
+    m2 = model.load_model(tmp_path / "w.npz")
+    for k in m.tensors:
+        np.testing.assert_array_equal(m.tensors[k], m2.tensors[k])
+    assert model.flatten_size(11, 128) == (1, 30, 1920) and model.flatten_size(11, 64)[2] == 896
+    bad = dict(m.tensors)
+    bad["conv2_w"] = bad["conv2_w"][..., :16]
+    with pytest.raises(ValueError):
+        model.F2CNNModel(bad)
+
+
+def test_cli_parser():
+    p = cli.build_parser()
+    a = p.parse_args(["prepare", "envelope", "--cutoff", "50"])
+    assert a.prepare_command == "envelope" and a.CUTOFF == 50
+    a = p.parse_args(["prepare", "input", "-l", "x.csv", "-i", "y.npy"])
+    assert a.labelFile == "x.csv" and a.inputFile == "y.npy" and a.CUTOFF is None
+    a = p.parse_args(["cnn", "eval", "-f", "a.WAV", "--lpf", "50", "-m", "w.npz"])
+    assert a.cnn_command == "eval" and a.file == "a.WAV" and a.CUTOFF == 50 and a.model == "w.npz"
+    with pytest.raises(SystemExit):
+        p.parse_args(["prepare", "organize"])
+    assert cli.main([]) == 1
+
+
+def test_empty_corpus_exits_like_the_reference(tmp_path, monkeypatch, capsys):
+    monkeypatch.chdir(tmp_path)
+    from f2cnn_amd.scripts.processing import GammatoneFiltering
+    with pytest.raises(SystemExit) as e:
+        GammatoneFiltering.FilterAllOrganisedFiles()
+    assert e.value.code == -1 and "NO WAV FILES FOUND" in capsys.readouterr().out
+    with pytest.raises(SystemExit):
+        EnvelopeExtraction.ExtractAllEnvelopes()
+    with pytest.raises(SystemExit):
+        InputGenerator.GenerateInputData()
+
+
+def test_shard_partition():
+    files = [f"f{i:03d}" for i in range(23)]
+    for world in (1, 2, 3, 8):
+        parts = [runtime.shard(files, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == files
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
