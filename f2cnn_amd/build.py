@@ -10,6 +10,9 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libf2cnn_hip.so")
 ARCH = "gfx950"
+# The FFT butterflies are scalar f32 code on register arrays; SLP-packing them into v_pk_*_f32 costs more
+# v_mov than it saves (packed f32 VALU has no rate advantage at >= 2 waves/SIMD on gfx950).
+PER_FILE_FLAGS = {"f2_envelope.hip": ("-fno-slp-vectorize",)}
 
 
 def hipcc_path():
@@ -41,7 +44,7 @@ def build_library(force=False, verbose=False, extra_flags=()):
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + ".o")
         cmd = [hipcc_path(), "-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-               *extra_flags, "-c", src, "-o", obj]
+               *PER_FILE_FLAGS.get(os.path.basename(src), ()), *extra_flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -3,23 +3,30 @@
 // ExtractEnvelopeFromMatrix).
 //
 // One 256-thread workgroup owns one (utterance, channel) row of n samples, zero-padded to
-// M = 2^ceil(log2 n) exactly as the reference does, and keeps the whole transform in LDS:
+// M = 2^ceil(log2 n) exactly as the reference does, and keeps the whole transform on chip:
 //
-//   1. pack the real row as H = M/2 complex points  z[m] = x[2m] + i x[2m+1]
-//   2. Z = FFT_H(z)             radix-8/16 Stockham passes, in place (all reads of a pass are held
-//                               in registers across the barrier), twiddles from a float64-built table
-//   3. the Hilbert transform h = H[x] is real, so its packed spectrum follows from Z by one pass
-//      over the pairs (k, H-k):  W[k] = i sin(t_k) Z[k] + cos(t_k) conj(Z[H-k]),  t_k = 2 pi k / M,
-//      W[0] = 0  (derivation in DESIGN.md); scipy.signal.hilbert's analytic signal is x + i h
-//   4. w = IFFT_H(W)  (run as conj(FFT(conj W)); only squares of w are used)  ->  h[2m] = Re w[m],
-//      h[2m+1] = Im w[m]
-//   5. env[n] = sqrt(x[n]^2 + h[n]^2); optional y[n] = b0 (env[n] + env[n-1]) - a1 y[n-1] in float64,
-//      time-parallel: each thread runs a contiguous chunk from zero state, the chunk-end values are
-//      combined by a multiplicative scan ((-a1)^L per chunk), and the chunk is re-run from its true
-//      initial state; the result is staged in LDS so that global stores are fully coalesced.
+//   1. the real row is read as H = M/2 complex points  z[m] = x[2m] + i x[2m+1]  (16-byte loads, coalesced)
+//      straight into the registers of the first FFT pass; for float transforms the thread keeps its x
+//      values for step 5
+//   2. Z = FFT_H(z): Stockham passes with a symmetric radix plan (a,b,a), e.g. 16-32-16 for H = 8192; data
+//      moves registers -> LDS -> registers -> LDS -> ..., every pass holds its inputs in registers across
+//      the barrier so the transform is in place; inter-pass twiddles come from per-pass tables laid out
+//      [k][butterfly / stride], i.e. coalesced (first pass) or near-uniform (later passes) loads
+//   3. the Hilbert transform h = H[x] is real, so its packed spectrum follows from Z by one pass over the
+//      pairs (k, H-k):  W[k] = i sin(t_k) Z[k] + cos(t_k) conj(Z[H-k]),  t_k = 2 pi k / M,  W[0] = 0
+//      (derivation in DESIGN.md); scipy.signal.hilbert's analytic signal is x + i h
+//   4. w = IFFT_H(W), run as conj(FFT(conj W)) (only squares of w are used); because first and last radix
+//      are equal, the last pass leaves in each thread exactly the points it loaded in step 1:
+//      h[2m] = Re w[m], h[2m+1] = Im w[m]
+//   5. env[n] = sqrt(x[n]^2 + h[n]^2) from registers; without low-pass it is stored at once (16-byte
+//      stores). With low-pass  y[n] = b0 (env[n] + env[n-1]) - a1 y[n-1]  runs in float64, time-parallel:
+//      each thread owns a contiguous chunk, runs it from zero state, the chunk-end values are combined by
+//      a multiplicative scan ((-a1)^L per chunk) and the chunk is re-run from its true initial state. The
+//      envelope sits TRANSPOSED in LDS (sample t*L+j at j*257+t) so the chunk sweeps and the coalesced
+//      copy-out are bank-conflict free.
 //
-// Two real FFTs of length M thus cost two complex FFTs of length M/2 on 8-byte (f32) points:
-// 64 KiB (+pad) of LDS for the 1 s / 16 kHz row of the benchmark, two workgroups per CU.
+// Two real FFTs of length M cost two complex FFTs of length M/2 on 8-byte (f32) points: 64 KiB (+pad) of
+// LDS for the 1 s / 16 kHz row of the benchmark, two workgroups per CU.
 // Bound: HBM, 16 bytes per sample-channel (8 read + 8 written).
 #include <cmath>
 
@@ -27,7 +34,9 @@
 
 namespace {
 
-constexpr int NT = 256;  // threads per workgroup
+// threads per workgroup: 256, or 512 where 256 threads would need more than 256 registers each
+template <typename F, int LOG2H>
+constexpr int threads_for() { return (sizeof(F) == 4 ? LOG2H >= 14 : LOG2H >= 13) ? 512 : 256; }
 
 template <typename F>
 struct cpx {
@@ -37,6 +46,8 @@ template <typename F>
 __device__ __forceinline__ cpx<F> operator+(cpx<F> a, cpx<F> b) { return {a.re + b.re, a.im + b.im}; }
 template <typename F>
 __device__ __forceinline__ cpx<F> operator-(cpx<F> a, cpx<F> b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ float fsqrt(float v) { return __builtin_amdgcn_sqrtf(v); }   // v_sqrt_f32, 1 ulp
+__device__ __forceinline__ double fsqrt(double v) { return sqrt(v); }
 template <typename F>
 __device__ __forceinline__ cpx<F> cmul(cpx<F> a, cpx<F> w) {
     return {a.re * w.re - a.im * w.im, a.re * w.im + a.im * w.re};
@@ -73,107 +84,135 @@ __device__ __forceinline__ cpx<F> mulw(cpx<F> a) {
     }
 }
 
-template <int R, int K, typename F>
-__device__ __forceinline__ void combine(cpx<F>* v, const cpx<F>* e, const cpx<F>* o) {
-    if constexpr (K < R / 2) {
-        const cpx<F> t = mulw<R, K>(o[K]);
-        v[K] = e[K] + t;
-        v[K + R / 2] = e[K] - t;
-        combine<R, K + 1>(v, e, o);
+template <int R, int J, typename F>
+__device__ __forceinline__ void dif_stage(cpx<F>* v) {
+    if constexpr (J < R / 2) {
+        const cpx<F> a = v[J], b = v[J + R / 2];
+        v[J] = a + b;
+        v[J + R / 2] = mulw<R, J>(a - b);
+        dif_stage<R, J + 1>(v);
     }
 }
 
-// forward DFT of R points held in registers, natural order in and out
+// forward DFT of R points held in registers, decimation in frequency, in place (no register shuffling):
+// natural order in, BIT-REVERSED order out: X[k] is left in v[brev<R>(k)]
 template <int R, typename F>
 __device__ __forceinline__ void dft(cpx<F>* v) {
-    if constexpr (R == 2) {
-        const cpx<F> a = v[0], b = v[1];
-        v[0] = a + b;
-        v[1] = a - b;
-    } else if constexpr (R > 2) {
-        cpx<F> e[R / 2], o[R / 2];
-#pragma unroll
-        for (int i = 0; i < R / 2; ++i) {
-            e[i] = v[2 * i];
-            o[i] = v[2 * i + 1];
-        }
-        dft<R / 2>(e);
-        dft<R / 2>(o);
-        combine<R, 0>(v, e, o);
+    if constexpr (R >= 2) {
+        dif_stage<R, 0>(v);
+        dft<R / 2>(v);
+        dft<R / 2>(v + R / 2);
     }
 }
 
-// pass plan: ceil(LOG2H/4) passes, bits spread evenly (13 -> 4,3,3,3; 12 -> 4,4,4)
-constexpr int plan_npass(int log2h) { return (log2h + 3) / 4; }
-constexpr int plan_bits(int log2h, int pass) {
-    const int np = plan_npass(log2h);
-    return np == 0 ? 0 : log2h / np + (pass < log2h % np ? 1 : 0);
-}
-constexpr int plan_shift(int log2h, int pass) {  // log2 of the stride entering `pass`
-    int s = 0;
-    for (int i = 0; i < pass; ++i) s += plan_bits(log2h, i);
-    return s;
+template <int R>
+constexpr int brev(int k) {
+    int r = 0;
+    for (int b = 1; b < R; b <<= 1) {
+        r = (r << 1) | (k & 1);
+        k >>= 1;
+    }
+    return r;
 }
 
-// LDS index padding of the complex array: one extra slot per 16 (keeps the stride-R writes of the
-// early passes off a single bank)
+// ---- radix plan: symmetric (first radix == last radix), radices 2..32 ----
+constexpr int plan_npass(int h) { return h == 0 ? 0 : h <= 5 ? 1 : h <= 10 ? ((h & 1) ? 3 : 2) : 3; }
+constexpr int plan_bits(int h, int pass) {
+    if (h <= 5) return h;
+    if (h <= 10) return (h & 1) ? (pass == 1 ? 1 : (h - 1) / 2) : h / 2;
+    const int a = h <= 13 ? 4 : 5;
+    return pass == 1 ? h - 2 * a : a;
+}
+constexpr int plan_shift(int h, int pass) {  // log2 of the stride entering `pass`
+    int s = 0;
+    for (int i = 0; i < pass; ++i) s += plan_bits(h, i);
+    return s;
+}
+// per-pass twiddle table: entry (k-1)*(NB/S) + p holds exp(-2 pi i (p*S) k / H), p < NB/S, 1 <= k < R
+constexpr int plan_tw_count(int h, int pass) {
+    const int R = 1 << plan_bits(h, pass), S = 1 << plan_shift(h, pass), H = 1 << h;
+    return S * R == H ? 0 : (R - 1) * (H / R / S);
+}
+constexpr int plan_tw_offset(int h, int pass) {
+    int o = 0;
+    for (int i = 0; i < pass; ++i) o += plan_tw_count(h, i);
+    return o;
+}
+constexpr int plan_tw_total(int h) { return plan_tw_offset(h, plan_npass(h)); }   // then H/2+1 entries of V
+
+// LDS index padding of the complex array: one extra slot per 16
 __device__ __forceinline__ int cpad(int i) { return i + (i >> 4); }
 constexpr int cpad_size(int h) { return h + (h >> 4) + 1; }
 
-// exp(-2 pi i t / H) from the half-circle table V[k] = exp(-2 pi i k / M), k < H
-template <typename F, int LOG2H>
-__device__ __forceinline__ cpx<F> twiddle_h(const cpx<F>* __restrict__ V, int t) {
+// One Stockham pass. SRC_REGS: inputs are already in v (first pass, loaded from global memory);
+// DST_REGS: outputs stay in v (last pass of the inverse transform). v is indexed [i*R + j] with
+// butterfly bf = tid + i*NT and point bf + j*NB.
+template <typename F, int LOG2H, int PASS, bool SRC_REGS, bool DST_REGS, int PTV, int NT>
+__device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__ tw, int tid, cpx<F> (&v)[PTV]) {
     constexpr int H = 1 << LOG2H;
-    const int u = 2 * t;
-    if (u < H) return V[u];
-    const cpx<F> w = V[u - H];
-    return {-w.re, -w.im};
-}
-
-template <typename F, int LOG2H, int PASS>
-__device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__ V, int tid) {
-    constexpr int H = 1 << LOG2H;
-    constexpr int LOG2R = plan_bits(LOG2H, PASS);
-    constexpr int R = 1 << LOG2R;
-    constexpr int S = 1 << plan_shift(LOG2H, PASS);
+    constexpr int R = 1 << plan_bits(LOG2H, PASS);
+    constexpr int LOG2S = plan_shift(LOG2H, PASS);
+    constexpr int S = 1 << LOG2S;
     constexpr int NB = H / R;
     constexpr int ITER = (NB + NT - 1) / NT;
     constexpr bool LAST = (S * R == H);
-    cpx<F> v[ITER][R];
+    static_assert(ITER * R <= PTV, "register array too small");
+    constexpr bool FULL = NB % NT == 0;   // every thread owns ITER whole butterflies: no guards
+    const cpx<F>* __restrict__ twp = tw + plan_tw_offset(LOG2H, PASS);
+    if constexpr (!SRC_REGS) {
 #pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-        const int bf = tid + i * NT;
-        if (bf < NB) {
+        for (int i = 0; i < ITER; ++i) {
+            const int bf = tid + i * NT;
+            if (FULL || bf < NB) {
+                // cpad(bf + j*NB) = cpad(bf) + j*(NB + NB/16) when 16 | NB: one base + immediate offsets
+                if constexpr (NB % 16 == 0) {
+                    const cpx<F>* src = lds + cpad(bf);
 #pragma unroll
-            for (int j = 0; j < R; ++j) v[i][j] = lds[cpad(bf + j * NB)];
+                    for (int j = 0; j < R; ++j) v[i * R + j] = src[j * (NB + NB / 16)];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) v[i * R + j] = lds[cpad(bf + j * NB)];
+                }
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
         const int bf = tid + i * NT;
-        if (bf < NB) {
-            dft<R>(v[i]);
-            const int q = bf & (S - 1);
-            const int ps = bf - q;  // p * S
-            const int base = q + ps * R;
-            lds[cpad(base)] = v[i][0];
+        if (FULL || bf < NB) {
+            dft<R>(&v[i * R]);   // X[k] now sits in v[i*R + brev<R>(k)]
+            if constexpr (!LAST) {
+                const cpx<F>* twq = twp + (bf >> LOG2S);
 #pragma unroll
-            for (int k = 1; k < R; ++k) {
-                cpx<F> o = v[i][k];
-                if constexpr (!LAST) o = cmul(o, twiddle_h<F, LOG2H>(V, ps * k));
-                lds[cpad(base + S * k)] = o;
+                for (int k = 1; k < R; ++k)
+                    v[i * R + brev<R>(k)] = cmul(v[i * R + brev<R>(k)], twq[(k - 1) * (NB / S)]);
+            }
+            if constexpr (!DST_REGS) {
+                const int q = bf & (S - 1);
+                const int base = q + (bf - q) * R;
+                if constexpr (S % 16 == 0) {
+                    cpx<F>* dst = lds + cpad(base);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) dst[k * (S + S / 16)] = v[i * R + brev<R>(k)];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) lds[cpad(base + S * k)] = v[i * R + brev<R>(k)];
+                }
             }
         }
     }
-    __syncthreads();
+    if constexpr (!DST_REGS) __syncthreads();
 }
 
-template <typename F, int LOG2H, int PASS = 0>
-__device__ __forceinline__ void fft_all(cpx<F>* lds, const cpx<F>* __restrict__ V, int tid) {
-    if constexpr (PASS < plan_npass(LOG2H)) {
-        fft_pass<F, LOG2H, PASS>(lds, V, tid);
-        fft_all<F, LOG2H, PASS + 1>(lds, V, tid);
+template <typename F, int LOG2H, bool INVERSE, int PTV, int NT, int PASS = 0>
+__device__ __forceinline__ void fft_all(cpx<F>* lds, const cpx<F>* __restrict__ tw, int tid, cpx<F> (&v)[PTV]) {
+    constexpr int NP = plan_npass(LOG2H);
+    if constexpr (PASS < NP) {
+        constexpr bool SRC = !INVERSE && PASS == 0;
+        constexpr bool DST = INVERSE && PASS == NP - 1;
+        fft_pass<F, LOG2H, PASS, SRC, DST, PTV, NT>(lds, tw, tid, v);
+        fft_all<F, LOG2H, INVERSE, PTV, NT, PASS + 1>(lds, tw, tid, v);
     }
 }
 
@@ -195,7 +234,8 @@ struct EnvParams {
 };
 
 template <typename F, int LOG2H>
-__global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __restrict__ V) {
+__global__ __launch_bounds__((threads_for<F, LOG2H>()), (sizeof(F) == 4 && LOG2H <= 13 ? 2 : 1)) void k_envelope(EnvParams P, const cpx<F>* __restrict__ tw) {
+    constexpr int NT = threads_for<F, LOG2H>();
     constexpr int H = 1 << LOG2H;
     constexpr int M = 2 * H;
     constexpr int CS = cpad_size(H);
@@ -203,10 +243,20 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
     constexpr int TP = NT + 1;                // row pitch of the transposed envelope image
     constexpr int RS = L * TP;
     constexpr int LDS_BYTES = (CS * 2 > RS ? CS * 2 : RS) * (int)sizeof(F);
+    // register shape of the first/last pass
+    constexpr int R0 = 1 << plan_bits(LOG2H, 0);
+    constexpr int NB0 = H / R0;
+    constexpr int ITER0 = (NB0 + NT - 1) / NT;
+    constexpr int RMAX = 1 << (plan_npass(LOG2H) == 3 && plan_bits(LOG2H, 1) > plan_bits(LOG2H, 0) ? plan_bits(LOG2H, 1)
+                                                                                                   : plan_bits(LOG2H, 0));
+    constexpr int PTMID = ((H / RMAX + NT - 1) / NT) * RMAX;
+    constexpr int PT = ITER0 * R0 > PTMID ? ITER0 * R0 : PTMID;   // complex points per thread (all passes)
+    constexpr bool KEEP_X = sizeof(F) == 4 && 2 * ITER0 * R0 <= 64;   // x stays in registers for step 5
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     __shared__ double wave_tot[NT / 64];
     cpx<F>* lds = reinterpret_cast<cpx<F>*>(smem);
     F* rl = reinterpret_cast<F*>(smem);
+    const cpx<F>* __restrict__ V = tw + plan_tw_total(LOG2H);   // exp(-2 pi i k / M), k <= H/2
 
     const int tid = threadIdx.x;
     const int u = blockIdx.x / P.C;
@@ -217,17 +267,56 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
     const size_t row = (size_t)P.C * (size_t)off + (size_t)c * (size_t)n;
     const double* __restrict__ x = P.gfb + row;
     double* __restrict__ y = P.env + row;
+    const bool al16 = (row & 1) == 0;   // row start is 16-byte aligned
 
-    // 1. pack
-    for (int m = tid; m < H; m += NT) {
-        const int i0 = 2 * m;
-        const F a = i0 < n ? (F)x[i0] : F(0);
-        const F bb = i0 + 1 < n ? (F)x[i0 + 1] : F(0);
-        lds[cpad(m)] = {a, bb};
+    // 1. load: point (i, j) of this thread is m = tid + i*NT + j*NB0
+    constexpr bool FULL0 = NB0 % NT == 0;
+    cpx<F> v[PT];
+    [[maybe_unused]] F xr[KEEP_X ? ITER0 * R0 : 1], xi[KEEP_X ? ITER0 * R0 : 1];
+    if (al16 && (n & 1) == 0 && n >= 2) {
+        // common case: 16-byte loads, no branches (clamped address + select for the zero padding)
+#pragma unroll
+        for (int i = 0; i < ITER0; ++i) {
+            const int bf = tid + i * NT;
+            if (FULL0 || bf < NB0) {
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const int i0 = 2 * (bf + j * NB0);
+                    const double2 t = *reinterpret_cast<const double2*>(x + min(i0, n - 2));
+                    const F a = i0 < n ? (F)t.x : F(0), bb = i0 < n ? (F)t.y : F(0);
+                    v[i * R0 + j] = {a, bb};
+                    if constexpr (KEEP_X) {
+                        xr[i * R0 + j] = a;
+                        xi[i * R0 + j] = bb;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITER0; ++i) {
+            const int bf = tid + i * NT;
+            if (FULL0 || bf < NB0) {
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const int i0 = 2 * (bf + j * NB0);
+                    const F a = i0 < n ? (F)x[i0] : F(0);
+                    const F bb = i0 + 1 < n ? (F)x[i0 + 1] : F(0);
+                    v[i * R0 + j] = {a, bb};
+                    if constexpr (KEEP_X) {
+                        xr[i * R0 + j] = a;
+                        xi[i * R0 + j] = bb;
+                    }
+                }
+            }
+        }
     }
-    __syncthreads();
-    // 2. forward transform
-    fft_all<F, LOG2H>(lds, V, tid);
+    // 2. forward transform (first pass straight from the registers)
+    fft_all<F, LOG2H, false, PT, NT>(lds, tw, tid, v);
+    if constexpr (LOG2H == 0) {
+        if (tid == 0) lds[0] = v[0];
+        __syncthreads();
+    }
     // 3. packed spectrum of the Hilbert transform, conjugated and scaled by 1/H for step 4
     {
         const F sc = F(1.0 / H);
@@ -253,52 +342,80 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
         }
     }
     __syncthreads();
-    // 4. inverse transform (forward transform of the conjugate)
-    fft_all<F, LOG2H>(lds, V, tid);
+    // 4. inverse transform (forward transform of the conjugate); outputs stay in v
+    fft_all<F, LOG2H, true, PT, NT>(lds, tw, tid, v);
+    if constexpr (LOG2H == 0) {
+        v[0] = lds[0];
+        __syncthreads();
+    }
 
-    // 5. magnitude (in F: the FFT already limits the accuracy to F)
-    constexpr int PT = (H + NT - 1) / NT;  // packed points per thread
-    if (!P.lpf) {
-#pragma unroll 4
-        for (int m = tid; m < H; m += NT) {
-            const cpx<F> w = lds[cpad(m)];
-            const int i0 = 2 * m;
-            if (i0 < n) {
-                const F a = (F)x[i0];
-                y[i0] = (double)sqrt(a * a + w.re * w.re);
+    // 5. magnitude (in F: the FFT already limits the accuracy to F). The last pass left point j of
+    //    butterfly i in v[i*R0 + brev(j)]; the envelope pair replaces it there.
+#pragma unroll
+    for (int i = 0; i < ITER0; ++i) {
+        const int bf = tid + i * NT;
+        if (FULL0 || bf < NB0) {
+#pragma unroll
+            for (int j = 0; j < R0; ++j) {
+                const int i0 = 2 * (bf + j * NB0);
+                F a, bb;
+                if constexpr (KEEP_X) {
+                    a = xr[i * R0 + j];
+                    bb = xi[i * R0 + j];
+                } else {
+                    a = i0 < n ? (F)x[i0] : F(0);
+                    bb = i0 + 1 < n ? (F)x[i0 + 1] : F(0);
+                }
+                const cpx<F> w = v[i * R0 + brev<R0>(j)];
+                v[i * R0 + brev<R0>(j)] = {fsqrt(a * a + w.re * w.re), fsqrt(bb * bb + w.im * w.im)};
             }
-            if (i0 + 1 < n) {
-                const F a = (F)x[i0 + 1];
-                y[i0 + 1] = (double)sqrt(a * a + w.im * w.im);
+        }
+    }
+    if (!P.lpf) {
+        if (al16 && (n & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < ITER0; ++i) {
+                const int bf = tid + i * NT;
+                if (FULL0 || bf < NB0) {
+#pragma unroll
+                    for (int j = 0; j < R0; ++j) {
+                        const int i0 = 2 * (bf + j * NB0);
+                        const cpx<F> e = v[i * R0 + brev<R0>(j)];
+                        if (i0 < n) *reinterpret_cast<double2*>(y + i0) = make_double2((double)e.re, (double)e.im);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITER0; ++i) {
+                const int bf = tid + i * NT;
+                if (FULL0 || bf < NB0) {
+#pragma unroll
+                    for (int j = 0; j < R0; ++j) {
+                        const int i0 = 2 * (bf + j * NB0);
+                        const cpx<F> e = v[i * R0 + brev<R0>(j)];
+                        if (i0 < n) y[i0] = (double)e.re;
+                        if (i0 + 1 < n) y[i0 + 1] = (double)e.im;
+                    }
+                }
             }
         }
         return;
     }
-    // With the low-pass the envelope goes back to LDS, TRANSPOSED: thread t will own the contiguous
-    // samples [t*L, (t+1)*L), so sample n = t*L + j is kept at j*TP + t (TP = 257: conflict-free for
-    // the per-chunk sweeps and for the coalesced copy-out, 2-way on this scatter).
+    // With the low-pass the envelope goes to LDS, TRANSPOSED: thread t will own the contiguous samples
+    // [t*L, (t+1)*L), so sample t*L + j is kept at j*TP + t. (The last FFT pass ended with a barrier after
+    // its LDS reads, so the array is free.)
     auto tpos = [](int i) { return (i % L) * TP + i / L; };
-    F e0[PT], e1[PT];
 #pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int m = tid + j * NT;
-        e0[j] = e1[j] = F(0);
-        if (m < H) {
-            const cpx<F> w = lds[cpad(m)];
-            const int i0 = 2 * m;
-            const F a = i0 < n ? (F)x[i0] : F(0);
-            const F bb = i0 + 1 < n ? (F)x[i0 + 1] : F(0);
-            e0[j] = sqrt(a * a + w.re * w.re);
-            e1[j] = sqrt(bb * bb + w.im * w.im);
-        }
-    }
-    __syncthreads();
+    for (int i = 0; i < ITER0; ++i) {
+        const int bf = tid + i * NT;
+        if (FULL0 || bf < NB0) {
 #pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int m = tid + j * NT;
-        if (m < H) {
-            rl[tpos(2 * m)] = e0[j];
-            rl[tpos(2 * m + 1)] = e1[j];
+            for (int j = 0; j < R0; ++j) {
+                const int i0 = 2 * (bf + j * NB0);
+                rl[tpos(i0)] = v[i * R0 + brev<R0>(j)].re;
+                rl[tpos(i0 + 1)] = v[i * R0 + brev<R0>(j)].im;
+            }
         }
     }
     __syncthreads();
@@ -323,15 +440,15 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
     for (int s = 1; s < L; s <<= 1) g *= g;
     // inclusive scan inside the wave: v_t = sum_{j<=t} g^(t-j) yz_j
     const int lane = tid & 63, wv = tid >> 6;
-    double v = yz, gd = g;
+    double sc = yz, gd = g;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const double up = shfl_up_f64(v, d);
-        if (lane >= d) v = fma(gd, up, v);
+        const double up = shfl_up_f64(sc, d);
+        if (lane >= d) sc = fma(gd, up, sc);
         gd *= gd;
     }
     // gd == g^64 now
-    if (lane == 63) wave_tot[wv] = v;
+    if (lane == 63) wave_tot[wv] = sc;
     __syncthreads();
     double carry = 0.0;  // true y at the end of the previous wave's last chunk
     for (int w2 = 0; w2 < wv; ++w2) carry = fma(gd, carry, wave_tot[w2]);
@@ -341,7 +458,7 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
         if (bits & 1) gl *= gp;
         gp *= gp;
     }
-    const double incl = fma(gl, carry, v);                  // true y at the end of this chunk
+    const double incl = fma(gl, carry, sc);                 // true y at the end of this chunk
     double yprev = shfl_up_f64(incl, 1);                    // ... of the previous chunk
     if (lane == 0) yprev = carry;
     {
@@ -355,8 +472,18 @@ __global__ __launch_bounds__(NT) void k_envelope(EnvParams P, const cpx<F>* __re
         }
     }
     __syncthreads();
+    if (al16) {
 #pragma unroll 4
-    for (int i = tid; i < n; i += NT) y[i] = (double)rl[tpos(i)];
+        for (int i = 2 * tid; i < n; i += 2 * NT) {
+            if (i + 1 < n)
+                *reinterpret_cast<double2*>(y + i) = make_double2((double)rl[tpos(i)], (double)rl[tpos(i + 1)]);
+            else
+                y[i] = (double)rl[tpos(i)];
+        }
+    } else {
+#pragma unroll 4
+        for (int i = tid; i < n; i += NT) y[i] = (double)rl[tpos(i)];
+    }
 }
 
 template <typename F>
@@ -376,18 +503,31 @@ EnvKernel<F> kernel_for(int log2h) {
 constexpr int MAX_LOG2H_F32 = 14;  // rows up to 32768 samples
 constexpr int MAX_LOG2H_F64 = 13;  // rows up to 16384 samples
 
+// host: per-pass twiddle tables followed by V[k] = exp(-2 pi i k / M), k <= H/2 (long double trigonometry)
 template <typename F>
 int ensure_twiddles(f2_ctx* ctx, int log2h, f2_scratch& slot) {
     if (slot.ptr) return F2_OK;
     const int H = 1 << log2h;
-    std::vector<cpx<F>> host((size_t)H);
-    const long double step = 2.0L * 3.14159265358979323846264338327950288L / (long double)(2 * H);
-    for (int k = 0; k < H; ++k) {
-        host[k].re = (F)cosl(step * k);
-        host[k].im = (F)(-sinl(step * k));
+    const long double tau = 2.0L * 3.14159265358979323846264338327950288L;
+    std::vector<cpx<F>> host;
+    host.reserve((size_t)plan_tw_total(log2h) + H / 2 + 1);
+    for (int pass = 0; pass < plan_npass(log2h); ++pass) {
+        const int R = 1 << plan_bits(log2h, pass), S = 1 << plan_shift(log2h, pass);
+        if (S * R == H) continue;
+        const int np = H / R / S;
+        for (int k = 1; k < R; ++k)
+            for (int p = 0; p < np; ++p) {
+                const long double ang = tau * (long double)((int64_t)p * S * k % H) / (long double)H;
+                host.push_back({(F)cosl(ang), (F)(-sinl(ang))});
+            }
     }
-    F2_TRY(f2_reserve(ctx, slot, sizeof(cpx<F>) * (size_t)H));
-    F2_HIP(ctx, hipMemcpyAsync(slot.ptr, host.data(), sizeof(cpx<F>) * (size_t)H, hipMemcpyHostToDevice, ctx->stream));
+    if ((int)host.size() != plan_tw_total(log2h)) return f2_fail(ctx, F2_ERR_INVALID, "twiddle plan mismatch");
+    for (int k = 0; k <= H / 2; ++k) {
+        const long double ang = tau * (long double)k / (long double)(2 * H);
+        host.push_back({(F)cosl(ang), (F)(-sinl(ang))});
+    }
+    F2_TRY(f2_reserve(ctx, slot, sizeof(cpx<F>) * host.size()));
+    F2_HIP(ctx, hipMemcpyAsync(slot.ptr, host.data(), sizeof(cpx<F>) * host.size(), hipMemcpyHostToDevice, ctx->stream));
     F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return F2_OK;
 }
@@ -445,7 +585,8 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         if (g.empty()) continue;
         P.ulist = identity ? nullptr : d_lists + pos;
         pos += g.size();
-        const dim3 grid((unsigned)(g.size() * (size_t)C)), block(NT);
+        const int nthreads = (precision == F2_FFT_F32 ? log2h >= 14 : log2h >= 13) ? 512 : 256;   // threads_for<F, LOG2H>()
+        const dim3 grid((unsigned)(g.size() * (size_t)C)), block(nthreads);
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
         if (precision == F2_FFT_F32) {
             F2_TRY(ensure_twiddles<float>(ctx, log2h, ctx->tw[0][log2h]));

@@ -30,8 +30,8 @@ def test_golden(golden, tag, precision, tol):
         assert err <= tol, (tag, lpf, err)
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 64, 100, 255, 256, 257, 511, 513, 1024, 2049,
-                               8192, 8193, 16384])
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 64, 65, 100, 128, 255, 256, 257, 511, 513, 1024,
+                               1500, 2048, 2049, 4096, 5000, 8192, 8193, 16001, 16384])
 def test_all_fft_sizes(N):
     rng = np.random.default_rng(N)
     m = rng.standard_normal((3, N)) * np.array([[1.0], [1e-6], [3000.0]])
@@ -41,10 +41,12 @@ def test_all_fft_sizes(N):
         assert chan_relerr(EE.ExtractEnvelopeFromMatrix(m, lpf, 50, precision=_lib.FFT_F32), ref) <= TOL
 
 
-def test_fft32_longest_row():
-    m = np.random.default_rng(5).standard_normal((2, 30000))
-    ref = orc.extract_envelope_from_matrix(m, True, 50)
-    assert chan_relerr(EE.ExtractEnvelopeFromMatrix(m, True, 50, precision=_lib.FFT_F32), ref) <= TOL
+@pytest.mark.parametrize("N", [16385, 20000, 30000, 32767, 32768])
+def test_fft32_longest_rows(N):
+    m = np.random.default_rng(5).standard_normal((2, N))
+    for lpf in (False, True):
+        ref = orc.extract_envelope_from_matrix(m, lpf, 50)
+        assert chan_relerr(EE.ExtractEnvelopeFromMatrix(m, lpf, 50, precision=_lib.FFT_F32), ref) <= TOL
 
 
 def test_too_long_is_reported_not_wrong():
