@@ -410,14 +410,16 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
         d_env = (double*)ctx->stage_out.ptr;
         d_gfb = gfb_or_null ? (double*)ctx->stage_aux.ptr : nullptr;
     }
-    // v0 of the fused path: the filterbank writes straight into the ENV buffer (or the GFB buffer when
-    // that output is wanted) and the envelope kernel runs in place / from it, so no third buffer and
-    // no host round trip; both launches are queued back to back on the context's stream.
+    // Two launches queued back to back on the context's stream, no third buffer and no host round trip.
+    // When the float64 filterbank output is not wanted and the envelope runs its float32 FFT, the filterbank
+    // hands its rows over as float32 inside the ENV buffer itself (half the bytes written and read back;
+    // the envelope kernel converts to float32 before its FFT anyway, so the result is bit-identical).
+    const bool f32_handoff = !d_gfb && f2_envelope_accepts_f32(offsets, B, fft_precision);
     double* k1_out = d_gfb ? d_gfb : d_env;
     F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
-                                (const double*)ctx->coefs.ptr, B, C, k1_out));
+                                (const double*)ctx->coefs.ptr, B, C, k1_out, f32_handoff));
     F2_TRY(f2_launch_envelope(ctx, k1_out, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz,
-                              fft_precision, d_env));
+                              fft_precision, d_env, f32_handoff));
     if (mem_space == F2_MEM_HOST) {
         F2_HIP(ctx, hipMemcpyAsync(env, d_env, bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (gfb_or_null) F2_HIP(ctx, hipMemcpyAsync(gfb_or_null, d_gfb, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -230,6 +230,7 @@ struct EnvParams {
     const int* ulist;  // utterances served by this launch (NULL: identity)
     int C;
     int lpf;
+    int f32_in;        // input rows are float32 at the start of their float64 slot (hand-off from K1)
     double b0, a1;     // y[n] = b0 (e[n] + e[n-1]) - a1 y[n-1]
 };
 
@@ -273,7 +274,46 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (sizeof(F) == 4 && LOG2H
     constexpr bool FULL0 = NB0 % NT == 0;
     cpx<F> v[PT];
     [[maybe_unused]] F xr[KEEP_X ? ITER0 * R0 : 1], xi[KEEP_X ? ITER0 * R0 : 1];
-    if (al16 && (n & 1) == 0 && n >= 2) {
+    if (KEEP_X && P.f32_in) {
+        // float32 hand-off from the filterbank kernel: the row's samples sit at the start of its float64 slot
+        const float* __restrict__ xf = reinterpret_cast<const float*>(x);
+        // branch-free (clamped address + select) so that all loads are in flight together
+        const int last = n - 1;
+        if ((n & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < ITER0; ++i) {
+                const int bf = tid + i * NT;
+                if (FULL0 || bf < NB0) {
+#pragma unroll
+                    for (int j = 0; j < R0; ++j) {
+                        const int i0 = 2 * (bf + j * NB0);
+                        const float2 t = *reinterpret_cast<const float2*>(xf + min(i0, n - 2));
+                        v[i * R0 + j] = {i0 < n ? (F)t.x : F(0), i0 < n ? (F)t.y : F(0)};
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITER0; ++i) {
+                const int bf = tid + i * NT;
+                if (FULL0 || bf < NB0) {
+#pragma unroll
+                    for (int j = 0; j < R0; ++j) {
+                        const int i0 = 2 * (bf + j * NB0);
+                        const float t0 = xf[min(i0, last)], t1 = xf[min(i0 + 1, last)];
+                        v[i * R0 + j] = {i0 < n ? (F)t0 : F(0), i0 + 1 < n ? (F)t1 : F(0)};
+                    }
+                }
+            }
+        }
+        if constexpr (KEEP_X) {
+#pragma unroll
+            for (int q = 0; q < ITER0 * R0; ++q) {
+                xr[q] = v[q].re;
+                xi[q] = v[q].im;
+            }
+        }
+    } else if (al16 && (n & 1) == 0 && n >= 2) {
         // common case: 16-byte loads, no branches (clamped address + select for the zero padding)
 #pragma unroll
         for (int i = 0; i < ITER0; ++i) {
@@ -300,8 +340,9 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (sizeof(F) == 4 && LOG2H
 #pragma unroll
                 for (int j = 0; j < R0; ++j) {
                     const int i0 = 2 * (bf + j * NB0);
-                    const F a = i0 < n ? (F)x[i0] : F(0);
-                    const F bb = i0 + 1 < n ? (F)x[i0 + 1] : F(0);
+                    const double t0 = x[min(i0, n - 1)], t1 = x[min(i0 + 1, n - 1)];   // clamped: no branches
+                    const F a = i0 < n ? (F)t0 : F(0);
+                    const F bb = i0 + 1 < n ? (F)t1 : F(0);
                     v[i * R0 + j] = {a, bb};
                     if constexpr (KEEP_X) {
                         xr[i * R0 + j] = a;
@@ -534,9 +575,19 @@ int ensure_twiddles(f2_ctx* ctx, int log2h, f2_scratch& slot) {
 
 }  // namespace
 
+bool f2_envelope_accepts_f32(const int64_t* h_offsets, int B, int precision) {
+    if (precision != F2_FFT_F32) return false;
+    for (int b = 0; b < B; ++b)
+        if (h_offsets[b + 1] - h_offsets[b] > (int64_t(2) << 13)) return false;   // KEEP_X kernels only (LOG2H <= 13)
+    return true;
+}
+
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
-                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env) {
+                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, bool f32_in) {
+    F2_CHECK(ctx, !f32_in || f2_envelope_accepts_f32(h_offsets, B, precision), F2_ERR_INVALID,
+             "float32 hand-off needs the float FFT and rows of at most 16384 samples");
     EnvParams P;
+    P.f32_in = f32_in ? 1 : 0;
     P.gfb = d_gfb;
     P.env = d_env;
     P.offsets = d_offsets;

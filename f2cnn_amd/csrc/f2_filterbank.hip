@@ -19,12 +19,17 @@ namespace {
 constexpr int TB = 32;                 // samples per LDS tile
 constexpr int ROWS_PER_STORE = 64 / TB;
 
-template <typename WaveT>
+// OutT = double: the (C,N) float64 matrix of the reference. OutT = float: the same row layout but each row's
+// float32 samples sit at the START of that row's float64 slot (row r, sample t -> float index 2*r*N + t), the
+// hand-off format to the float32-FFT envelope kernel, which then overwrites the slot with float64 envelopes.
+// A2ZERO: the numerators have no z^-2 term (always true for make_erb_filters output): 16 float64 ops per
+// sample-channel (the 1/gain factor is folded into the last section's numerator).
+template <typename WaveT, typename OutT, bool A2ZERO>
 __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__ wave,
                                                        const int64_t* __restrict__ offsets,
                                                        const double* __restrict__ coefs, int C,
                                                        int groups, double* __restrict__ out) {
-    __shared__ double tile[64][TB + 1];
+    __shared__ OutT tile[64][TB + 1];
     __shared__ double xs[TB];
 
     const int lane = threadIdx.x;
@@ -36,19 +41,24 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
 
     const int c = min(c0 + lane, C - 1);  // idle lanes shadow the last channel; their rows are never stored
     const double* k = coefs + (size_t)c * 10;
-    const double A0 = k[0], A11 = k[1], A12 = k[2], A13 = k[3], A14 = k[4];
-    const double A2 = k[5], B0 = k[6];
     // lfilter normalises by a[0]; make_erb_filters always emits B0 == 1 and A2 == 0, kept general here
-    const double rB0 = 1.0 / B0;
-    const double b0 = A0 * rB0, b2 = A2 * rB0, a1 = k[7] * rB0, a2 = k[8] * rB0;
-    const double b11 = A11 * rB0, b12 = A12 * rB0, b13 = A13 * rB0, b14 = A14 * rB0;
+    const double rB0 = 1.0 / k[6];
     const double inv_gain = 1.0 / k[9];
+    const double b0 = k[0] * rB0, b2 = k[5] * rB0, a1 = k[7] * rB0, a2 = k[8] * rB0;
+    const double b11 = k[1] * rB0, b12 = k[2] * rB0, b13 = k[3] * rB0;
+    // last section scaled by 1/gain: its output is the final sample
+    const double b0g = b0 * inv_gain, b14g = k[4] * rB0 * inv_gain, b2g = b2 * inv_gain;
 
     double z10 = 0, z11 = 0, z20 = 0, z21 = 0, z30 = 0, z31 = 0, z40 = 0, z41 = 0;
 
     const WaveT* w = wave + off;
-    double* o = out + (size_t)C * (size_t)off;
+    constexpr int ROWMUL = sizeof(double) / sizeof(OutT);   // row pitch in OutT elements = ROWMUL * N
+    char* obase = reinterpret_cast<char*>(out + (size_t)C * (size_t)off);
     const int srow = lane / TB, scol = lane % TB;
+    // byte offsets inside this utterance's block fit 32 bits up to 512 Mi sample-channels
+    const bool fits32 = (uint64_t)C * (uint64_t)N * 8u < (uint64_t(1) << 32);
+    const bool full_rows = c0 + 64 <= C;
+    const uint32_t rstep = (uint32_t)(ROWS_PER_STORE * N * ROWMUL * sizeof(OutT));
 
     for (int64_t t0 = 0; t0 < N; t0 += TB) {
         if (lane < TB) {
@@ -62,45 +72,72 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
             // section 1..4: y = b0*x + z0 ; z0 = b1*x - a1*y + z1 ; z1 = b2*x - a2*y
             const double y1 = fma(b0, x, z10);
             z10 = fma(-a1, y1, fma(b11, x, z11));
-            z11 = fma(b2, x, -a2 * y1);
+            z11 = A2ZERO ? -a2 * y1 : fma(b2, x, -a2 * y1);
             const double y2 = fma(b0, y1, z20);
             z20 = fma(-a1, y2, fma(b12, y1, z21));
-            z21 = fma(b2, y1, -a2 * y2);
+            z21 = A2ZERO ? -a2 * y2 : fma(b2, y1, -a2 * y2);
             const double y3 = fma(b0, y2, z30);
             z30 = fma(-a1, y3, fma(b13, y2, z31));
-            z31 = fma(b2, y2, -a2 * y3);
-            const double y4 = fma(b0, y3, z40);
-            z40 = fma(-a1, y4, fma(b14, y3, z41));
-            z41 = fma(b2, y3, -a2 * y4);
-            tile[lane][j] = y4 * inv_gain;
+            z31 = A2ZERO ? -a2 * y3 : fma(b2, y2, -a2 * y3);
+            const double y4 = fma(b0g, y3, z40);
+            z40 = fma(-a1, y4, fma(b14g, y3, z41));
+            z41 = A2ZERO ? -a2 * y4 : fma(b2g, y3, -a2 * y4);
+            tile[lane][j] = (OutT)y4;
         }
         __syncthreads();
-        const int64_t t = t0 + scol;
-        if (t < N) {
-#pragma unroll 8
+        if (fits32 && full_rows && t0 + TB <= N) {
+            // whole tile inside the matrix: one 32-bit offset add per store, no checks
+            uint32_t boff = (uint32_t)((((size_t)(c0 + srow) * (size_t)N) * ROWMUL + (size_t)(t0 + scol)) * sizeof(OutT));
+#pragma unroll 16
             for (int r = 0; r < 64; r += ROWS_PER_STORE) {
-                const int row = r + srow;
-                if (c0 + row < C) o[(size_t)(c0 + row) * (size_t)N + (size_t)t] = tile[row][scol];
+                *reinterpret_cast<OutT*>(obase + boff) = tile[r + srow][scol];
+                boff += rstep;
+            }
+        } else {
+            const int64_t t = t0 + scol;
+            if (t < N) {
+                OutT* o = reinterpret_cast<OutT*>(obase);
+#pragma unroll 8
+                for (int r = 0; r < 64; r += ROWS_PER_STORE) {
+                    const int row = r + srow;
+                    if (c0 + row < C) o[(size_t)(c0 + row) * (size_t)N * ROWMUL + (size_t)t] = tile[row][scol];
+                }
             }
         }
         __syncthreads();
     }
 }
 
+template <typename WaveT, typename OutT>
+void launch_fb(hipStream_t st, dim3 grid, bool a2zero, const void* wave, const int64_t* offsets, const double* coefs, int C,
+               int groups, double* out) {
+    if (a2zero)
+        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true>), grid, dim3(64), 0, st, (const WaveT*)wave, offsets, coefs, C,
+                           groups, out);
+    else
+        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, false>), grid, dim3(64), 0, st, (const WaveT*)wave, offsets, coefs,
+                           C, groups, out);
+}
+
 }  // namespace
 
 int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,
-                         const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb) {
+                         const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb, bool f32_out) {
     (void)h_offsets;
     const int groups = (C + 63) / 64;
-    const dim3 grid((unsigned)(B * groups)), block(64);
+    const dim3 grid((unsigned)(B * groups));
+    // the coefficient rows of this call are mirrored on the host by f2_upload_coefs
+    bool a2zero = ctx->coefs_host.size() == (size_t)C * 10;
+    for (int c = 0; a2zero && c < C; ++c) a2zero = ctx->coefs_host[(size_t)c * 10 + 5] == 0.0;
     F2_TRY(f2_prof_begin(ctx, F2_K_FILTERBANK));
-    if (wave_dtype == F2_WAVE_I16)
-        hipLaunchKernelGGL(k_erb_filterbank<int16_t>, grid, block, 0, ctx->stream, (const int16_t*)d_wave, d_offsets,
-                           d_coefs, C, groups, d_gfb);
+    if (wave_dtype == F2_WAVE_I16 && !f32_out)
+        launch_fb<int16_t, double>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
+    else if (wave_dtype == F2_WAVE_I16)
+        launch_fb<int16_t, float>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
+    else if (!f32_out)
+        launch_fb<double, double>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
     else
-        hipLaunchKernelGGL(k_erb_filterbank<double>, grid, block, 0, ctx->stream, (const double*)d_wave, d_offsets,
-                           d_coefs, C, groups, d_gfb);
+        launch_fb<double, float>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_FILTERBANK));
     return F2_OK;

@@ -91,9 +91,12 @@ static inline int f2_log2_ceil(int64_t n) {
 
 // ---- launchers implemented in the kernel translation units (device pointers only) ----
 int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,
-                         const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb);
+                         const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb,
+                         bool f32_out = false);
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
-                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env);
+                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, bool f32_in = false);
+// true when every utterance can take the float32 hand-off between K1 and K2 (float FFT, x kept in registers)
+bool f2_envelope_accepts_f32(const int64_t* h_offsets, int B, int precision);
 // d_centers == NULL: window e is centred at first_center + e
 int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const int64_t* d_centers,
                      int64_t first_center, int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag);
