@@ -36,7 +36,12 @@ namespace {
 
 // threads per workgroup: 256, or 512 where 256 threads would need more than 256 registers each
 template <typename F, int LOG2H>
-constexpr int threads_for() { return (sizeof(F) == 4 ? LOG2H >= 14 : LOG2H >= 13) ? 512 : 256; }
+constexpr int threads_for() { return LOG2H >= 13 ? 512 : 256; }
+// waves per SIMD the register allocator must leave room for (2 workgroups per CU wherever LDS allows)
+template <typename F, int LOG2H>
+constexpr int min_waves_for() {
+    return (sizeof(F) == 4 && LOG2H == 13) ? 4 : (sizeof(F) == 4 && LOG2H <= 12) ? 2 : (sizeof(F) == 8 && LOG2H <= 12) ? 2 : 2;
+}
 
 template <typename F>
 struct cpx {
@@ -116,12 +121,31 @@ constexpr int brev(int k) {
 }
 
 // ---- radix plan: symmetric (first radix == last radix), radices 2..32 ----
-constexpr int plan_npass(int h) { return h == 0 ? 0 : h <= 5 ? 1 : h <= 10 ? ((h & 1) ? 3 : 2) : 3; }
+// H = 8192 (the 1 s / 16 kHz row) runs as 16-8-4-16 on 512 threads: 16 points per thread in every pass keeps
+// the kernel under 128 registers, i.e. 16 waves per CU to hide LDS / barrier / HBM latency.
+#ifndef F2_PLAN13_PASSES
+#define F2_PLAN13_PASSES 4
+#endif
+constexpr int plan_npass(int h) {
+    return h == 0 ? 0 : h <= 5 ? 1 : h <= 10 ? ((h & 1) ? 3 : 2) : (h == 13 && F2_PLAN13_PASSES == 4) ? 4 : 3;
+}
 constexpr int plan_bits(int h, int pass) {
     if (h <= 5) return h;
     if (h <= 10) return (h & 1) ? (pass == 1 ? 1 : (h - 1) / 2) : h / 2;
+    if (h == 13 && F2_PLAN13_PASSES == 4) return pass == 1 ? 3 : pass == 2 ? 2 : 4;
     const int a = h <= 13 ? 4 : 5;
     return pass == 1 ? h - 2 * a : a;
+}
+// most complex points a thread holds in any pass
+constexpr int plan_points_per_thread(int h, int nt) {
+    int m = 1;
+    for (int p = 0; p < plan_npass(h); ++p) {
+        const int R = 1 << plan_bits(h, p);
+        const int nb = (1 << h) / R;
+        const int pts = ((nb + nt - 1) / nt) * R;
+        m = pts > m ? pts : m;
+    }
+    return m;
 }
 constexpr int plan_shift(int h, int pass) {  // log2 of the stride entering `pass`
     int s = 0;
@@ -235,7 +259,7 @@ struct EnvParams {
 };
 
 template <typename F, int LOG2H>
-__global__ __launch_bounds__((threads_for<F, LOG2H>()), (sizeof(F) == 4 && LOG2H <= 13 ? 2 : 1)) void k_envelope(EnvParams P, const cpx<F>* __restrict__ tw) {
+__global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>())) void k_envelope(EnvParams P, const cpx<F>* __restrict__ tw) {
     constexpr int NT = threads_for<F, LOG2H>();
     constexpr int H = 1 << LOG2H;
     constexpr int M = 2 * H;
@@ -248,10 +272,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (sizeof(F) == 4 && LOG2H
     constexpr int R0 = 1 << plan_bits(LOG2H, 0);
     constexpr int NB0 = H / R0;
     constexpr int ITER0 = (NB0 + NT - 1) / NT;
-    constexpr int RMAX = 1 << (plan_npass(LOG2H) == 3 && plan_bits(LOG2H, 1) > plan_bits(LOG2H, 0) ? plan_bits(LOG2H, 1)
-                                                                                                   : plan_bits(LOG2H, 0));
-    constexpr int PTMID = ((H / RMAX + NT - 1) / NT) * RMAX;
-    constexpr int PT = ITER0 * R0 > PTMID ? ITER0 * R0 : PTMID;   // complex points per thread (all passes)
+    constexpr int PT = plan_points_per_thread(LOG2H, NT);   // complex points per thread (all passes)
     constexpr bool KEEP_X = sizeof(F) == 4 && 2 * ITER0 * R0 <= 64;   // x stays in registers for step 5
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     __shared__ double wave_tot[NT / 64];
@@ -636,7 +657,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         if (g.empty()) continue;
         P.ulist = identity ? nullptr : d_lists + pos;
         pos += g.size();
-        const int nthreads = (precision == F2_FFT_F32 ? log2h >= 14 : log2h >= 13) ? 512 : 256;   // threads_for<F, LOG2H>()
+        const int nthreads = log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
         const dim3 grid((unsigned)(g.size() * (size_t)C)), block(nthreads);
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
         if (precision == F2_FFT_F32) {

@@ -60,37 +60,64 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
     const bool full_rows = c0 + 64 <= C;
     const uint32_t rstep = (uint32_t)(ROWS_PER_STORE * N * ROWMUL * sizeof(OutT));
 
+    // The input block is fetched one block ahead: vmcnt retires in issue order (stores included), so a load
+    // issued after a block's 32 row stores would make the wave wait for those stores every block.
+    WaveT xnext = (lane < TB && lane < N) ? w[lane] : WaveT(0);
     for (int64_t t0 = 0; t0 < N; t0 += TB) {
-        if (lane < TB) {
-            const int64_t t = t0 + lane;
-            xs[lane] = t < N ? (double)w[t] : 0.0;
+        if (lane < TB) xs[lane] = (double)xnext;
+        {
+            const int64_t t = t0 + TB + lane;
+            xnext = (lane < TB && t < N) ? w[t] : WaveT(0);
         }
         __syncthreads();
+        // The four sections of one sample form a dependent chain (y1 -> y2 -> y3 -> y4). The block is written
+        // out skewed -- step s runs section k on sample s-k+1 -- so that every step holds four independent
+        // recurrences and the in-order VALU always has a ready float64 FMA.
+        double p1 = 0, p2 = 0, p3 = 0;
 #pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const double x = xs[j];
-            // section 1..4: y = b0*x + z0 ; z0 = b1*x - a1*y + z1 ; z1 = b2*x - a2*y
-            const double y1 = fma(b0, x, z10);
-            z10 = fma(-a1, y1, fma(b11, x, z11));
-            z11 = A2ZERO ? -a2 * y1 : fma(b2, x, -a2 * y1);
-            const double y2 = fma(b0, y1, z20);
-            z20 = fma(-a1, y2, fma(b12, y1, z21));
-            z21 = A2ZERO ? -a2 * y2 : fma(b2, y1, -a2 * y2);
-            const double y3 = fma(b0, y2, z30);
-            z30 = fma(-a1, y3, fma(b13, y2, z31));
-            z31 = A2ZERO ? -a2 * y3 : fma(b2, y2, -a2 * y3);
-            const double y4 = fma(b0g, y3, z40);
-            z40 = fma(-a1, y4, fma(b14g, y3, z41));
-            z41 = A2ZERO ? -a2 * y4 : fma(b2g, y3, -a2 * y4);
-            tile[lane][j] = (OutT)y4;
+        for (int s2 = 0; s2 < TB + 3; ++s2) {
+            double n1 = 0, n2 = 0, n3 = 0;
+            if (s2 < TB) {
+                const double x = xs[s2];
+                // y = b0*x + z0 ; z0 = b1*x - a1*y + z1 ; z1 = b2*x - a2*y
+                const double y1 = fma(b0, x, z10);
+                z10 = fma(-a1, y1, fma(b11, x, z11));
+                z11 = A2ZERO ? -a2 * y1 : fma(b2, x, -a2 * y1);
+                n1 = y1;
+            }
+            if (s2 >= 1 && s2 - 1 < TB) {
+                const double y2 = fma(b0, p1, z20);
+                z20 = fma(-a1, y2, fma(b12, p1, z21));
+                z21 = A2ZERO ? -a2 * y2 : fma(b2, p1, -a2 * y2);
+                n2 = y2;
+            }
+            if (s2 >= 2 && s2 - 2 < TB) {
+                const double y3 = fma(b0, p2, z30);
+                z30 = fma(-a1, y3, fma(b13, p2, z31));
+                z31 = A2ZERO ? -a2 * y3 : fma(b2, p2, -a2 * y3);
+                n3 = y3;
+            }
+            if (s2 >= 3) {
+                const double y4 = fma(b0g, p3, z40);
+                z40 = fma(-a1, y4, fma(b14g, p3, z41));
+                z41 = A2ZERO ? -a2 * y4 : fma(b2g, p3, -a2 * y4);
+                tile[lane][s2 - 3] = (OutT)y4;
+            }
+            p1 = n1;
+            p2 = n2;
+            p3 = n3;
         }
         __syncthreads();
         if (fits32 && full_rows && t0 + TB <= N) {
             // whole tile inside the matrix: one 32-bit offset add per store, no checks
             uint32_t boff = (uint32_t)((((size_t)(c0 + srow) * (size_t)N) * ROWMUL + (size_t)(t0 + scol)) * sizeof(OutT));
-#pragma unroll 16
-            for (int r = 0; r < 64; r += ROWS_PER_STORE) {
-                *reinterpret_cast<OutT*>(obase + boff) = tile[r + srow][scol];
+            // all LDS reads first (distinct registers), then the stores: no load-use wait per row
+            OutT vals[64 / ROWS_PER_STORE];
+#pragma unroll
+            for (int q = 0; q < 64 / ROWS_PER_STORE; ++q) vals[q] = tile[q * ROWS_PER_STORE + srow][scol];
+#pragma unroll
+            for (int q = 0; q < 64 / ROWS_PER_STORE; ++q) {
+                *reinterpret_cast<OutT*>(obase + boff) = vals[q];
                 boff += rstep;
             }
         } else {
