@@ -111,6 +111,8 @@ def main():
     B = args.batch or {"cfg2": 256, "cfg3": 1000, "cfg4": 8}[args.workload]
     seed = seeds[args.workload]
     lpf = 50 if args.workload == "cfg3" else 0
+    if args.workload == "cfg4" and args.steps == 20 and args.warmup == 3:
+        args.steps, args.warmup = 3, 1
 
     waves = synth_batch(seed, rank * B, B, N)
     offsets = np.arange(B + 1, dtype=np.int64) * N
@@ -118,6 +120,8 @@ def main():
     ctx.h2d(d_wave, waves)
     d_out = ctx.malloc(8 * C * N * B)
 
+    CNN_FLOP_PER_WINDOW = 2 * 20990472          # SURVEY 8a row a13 (11 x 128 window)
+    bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
     if args.workload == "cfg2":
         def step():
             ctx.erb_filterbank_batch(d_wave, _lib.WAVE_I16, offsets, coefs, B, C, d_out, _lib.MEM_DEVICE)
@@ -127,12 +131,32 @@ def main():
         def step():
             ctx.filterbank_envelope_fused(d_wave, _lib.WAVE_I16, offsets, coefs, B, C, True, lpf, precision, d_out,
                                           None, _lib.MEM_DEVICE)
-        algo = {"k_erb_filterbank": B * (2 * N + 8 * C * N), "k_envelope": B * 16 * C * N,
-                "k_fused_filterbank_envelope": B * (2 * N + 8 * C * N)}
+        # float32 FFT: the filterbank hands its rows to the envelope kernel as float32 inside the ENV buffer
+        # (4 B written + 4 B read per sample-channel); float64 FFT: float64 hand-off (8 + 8)
+        h = 4 if args.fft == "f32" and N <= 16384 else 8
+        algo = {"k_erb_filterbank": B * (2 * N + h * C * N), "k_envelope": B * (h + 8) * C * N}
         label = (f"cfg3: fused filterbank + Hilbert envelope + {lpf} Hz LPF, batch of {B} x {N / FS:g} s utterances "
                  f"per GPU, {C} channels, ENV1 (float64) out")
     else:
-        raise SystemExit("cfg4 (cnn eval end to end) is benchmarked by tools/bench_cnn.py in this round")
+        from f2cnn_amd.model import F2CNNModel
+        if C != 128:
+            raise SystemExit("cfg4 uses the 11 x 128 network")
+        model = F2CNNModel.glorot(7)
+        hcnn = model.handle(ctx)
+        nb = N - 11 * 160
+        d_scores = ctx.malloc(8 * nb * B)
+        d_labels = ctx.malloc(nb * B)
+
+        def step():
+            for u in range(B):
+                ctx.eval_utterance(hcnn, d_wave + 2 * N * u, _lib.WAVE_I16, N, coefs, C, False, 0.0, precision, 5, 160,
+                                   None, d_scores + 8 * nb * u, d_labels + nb * u, _lib.MEM_DEVICE)
+        chunks = -(-nb // 4096)
+        algo = {"k_cnn_forward": CNN_FLOP_PER_WINDOW * nb / chunks, "k_gather_windows": 0,
+                "k_erb_filterbank": 2 * N + 8 * C * N, "k_envelope": 16 * C * N}
+        bound, peak, unit = "mfma", F32_PEAK_TFLOPS * 1e3, "GFLOP/s"
+        label = (f"cfg4: cnn eval end to end (filterbank, envelope, every-sample 11x{C} windows, normalise, CNN), "
+                 f"{B} x {N / FS:g} s utterances per GPU = {B * nb} windows, Glorot weights seed 7")
 
     def barrier():
         ctx.synchronize()
@@ -164,28 +188,40 @@ def main():
         kname, (launches, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
         avg_s = total_ms / launches / 1e3
         achieved = algo[kname] / avg_s / 1e9
+        pipeline_bytes = B * (2 * N + 8 * C * N)     # what the whole step must move at least (cfg2/cfg3)
         out = {
-            "metric": "audio-seconds/sec through filterbank+envelope (HIP, 1 MI355X per rank)",
+            "metric": "audio-seconds/sec through filterbank+envelope" + ("+CNN" if args.workload == "cfg4" else "")
+                      + " (HIP, 1 MI355X per rank)",
             "value": round(audio_s / elapsed, 1),
             "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if args.workload == "cfg2" else ("f64 IIR + %s FFT" % args.fft),
+            "dtype": "f64" if args.workload == "cfg2" else ("f64 IIR + %s FFT" % args.fft) + (
+                " + f32 CNN" if args.workload == "cfg4" else ""),
             "data": "synthetic",
             "config": {"workload": label, "batch_per_gpu": B, "channels": C, "samples_per_utterance": N,
                        "sample_rate": FS, "lpf_hz": lpf, "parallelism": f"utterance-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": algo[kname], "avg_launch_ms": round(avg_s * 1e3, 4),
-                         "launches_timed": launches},
+            "roofline": {"bound": bound, "kernel": kname, "achieved": round(achieved, 1), "peak": peak,
+                         "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
+                         ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_flop_per_launch"):
+                             algo[kname], "avg_launch_ms": round(avg_s * 1e3, 4), "launches_timed": launches},
             "kernels": {k: {"launches": n, "avg_ms": round(ms / n, 4),
-                            "algorithmic_GBps": round(algo[k] / (ms / n / 1e3) / 1e9, 1)} for k, (n, ms) in prof.items()},
+                            ("algorithmic_GBps" if k != "k_cnn_forward" else "algorithmic_GFLOPps"):
+                                round(algo[k] / (ms / n / 1e3) / 1e9, 1)} for k, (n, ms) in prof.items()},
         }
+        if args.workload != "cfg4":
+            out["pipeline"] = {"algorithmic_bytes_per_step": pipeline_bytes,
+                               "algorithmic_GBps": round(pipeline_bytes / (elapsed / args.steps) / 1e9, 1),
+                               "frac_of_hbm_peak": round(pipeline_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seed, N, C, lpf, "filterbank" if args.workload == "cfg2" else "both",
-                                               args.cpu_sample)
-            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            if args.workload == "cfg4":
+                out["cpu_baseline"] = None   # the CNN oracle (NumPy) is timed by tests only; no Keras on the box
+            else:
+                out["cpu_baseline"] = cpu_baseline(seed, N, C, lpf, "filterbank" if args.workload == "cfg2" else "both",
+                                                   args.cpu_sample)
+            if out["cpu_baseline"]:
+                out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
 
     ctx.free(d_wave)
