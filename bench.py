@@ -98,10 +98,18 @@ def main():
     from f2cnn_amd import _lib
     from f2cnn_amd.gammatone import filters
 
+    # one rank per GPU over RCCL; F2CNN_BENCH_BACKEND=gloo + F2CNN_BENCH_ONE_DEVICE=1 rehearse the multi-rank
+    # path on a single GPU (all ranks on device 0, CPU tensors for the barrier / MAX-reduce)
+    backend = os.environ.get("F2CNN_BENCH_BACKEND", "nccl")
+    if os.environ.get("F2CNN_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     ctx = _lib.Context(local)
     C, N = args.channels, args.samples
@@ -177,7 +185,7 @@ def main():
     prof = ctx.prof_get()
     ctx.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
