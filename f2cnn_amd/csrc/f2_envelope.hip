@@ -120,6 +120,11 @@ constexpr int brev(int k) {
     return r;
 }
 
+// Whether the Hilbert pair step is folded into the inverse transform's first pass (needs ~3x the pass's points in
+// registers for a moment: only where the register budget allows) or runs as its own sweep over LDS.
+template <typename F, int LOG2H>
+constexpr bool fuse_hilbert() { return LOG2H >= 1 && LOG2H <= 12 && sizeof(F) == 4; }
+
 // ---- radix plan: symmetric (first radix == last radix), radices 2..32 ----
 // H = 8192 (the 1 s / 16 kHz row) runs as 16-8-4-16 on 512 threads: 16 points per thread in every pass keeps
 // the kernel under 128 registers, i.e. 16 waves per CU to hide LDS / barrier / HBM latency.
@@ -171,7 +176,11 @@ constexpr int cpad_size(int h) { return h + (h >> 4) + 1; }
 // One Stockham pass. SRC_REGS: inputs are already in v (first pass, loaded from global memory);
 // DST_REGS: outputs stay in v (last pass of the inverse transform). v is indexed [i*R + j] with
 // butterfly bf = tid + i*NT and point bf + j*NB.
-template <typename F, int LOG2H, int PASS, bool SRC_REGS, bool DST_REGS, int PTV, int NT>
+// HILBERT (first pass of the inverse transform): the pass reads Z[m] and its mirror Z[H-m] and forms, in
+// registers, the conjugated and 1/H-scaled packed spectrum of the Hilbert transform
+//   W[m] = i sin(t_m) Z[m] + cos(t_m) conj(Z[H-m]),  t_m = 2 pi m / M,  W[0] = 0
+// so the spectrum never makes a separate trip through LDS.
+template <typename F, int LOG2H, int PASS, bool SRC_REGS, bool DST_REGS, int PTV, int NT, bool HILBERT = false>
 __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__ tw, int tid, cpx<F> (&v)[PTV]) {
     constexpr int H = 1 << LOG2H;
     constexpr int R = 1 << plan_bits(LOG2H, PASS);
@@ -196,6 +205,22 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
                 } else {
 #pragma unroll
                     for (int j = 0; j < R; ++j) v[i * R + j] = lds[cpad(bf + j * NB)];
+                }
+                if constexpr (HILBERT) {
+                    const cpx<F>* __restrict__ V = tw + plan_tw_total(LOG2H);   // (cos t_k, -sin t_k), k <= H/2
+                    const F sc = F(1.0 / H);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        const int m = bf + j * NB;
+                        // mirror point; cpad(H - m) = cpad(H - bf) - j*(NB + NB/16) when 16 | NB
+                        const cpx<F> zp = (NB % 16 == 0) ? (lds + cpad(H - bf))[-j * (NB + NB / 16)] : lds[cpad(H - m)];
+                        const bool upper = 2 * m > H;                  // t_m = pi - t_(H-m)
+                        const cpx<F> vk = V[upper ? H - m : m];
+                        const F cs = (upper ? -vk.re : vk.re) * sc, sn = -vk.im * sc;
+                        const cpx<F> z = v[i * R + j];
+                        const F wre = cs * zp.re - sn * z.im, wim = sn * z.re - cs * zp.im;
+                        v[i * R + j] = {m == 0 ? F(0) : wre, m == 0 ? F(0) : -wim};
+                    }
                 }
             }
         }
@@ -235,7 +260,7 @@ __device__ __forceinline__ void fft_all(cpx<F>* lds, const cpx<F>* __restrict__ 
     if constexpr (PASS < NP) {
         constexpr bool SRC = !INVERSE && PASS == 0;
         constexpr bool DST = INVERSE && PASS == NP - 1;
-        fft_pass<F, LOG2H, PASS, SRC, DST, PTV, NT>(lds, tw, tid, v);
+        fft_pass<F, LOG2H, PASS, SRC, DST, PTV, NT, INVERSE && PASS == 0 && fuse_hilbert<F, LOG2H>()>(lds, tw, tid, v);
         fft_all<F, LOG2H, INVERSE, PTV, NT, PASS + 1>(lds, tw, tid, v);
     }
 }
@@ -247,6 +272,20 @@ __device__ __forceinline__ double shfl_up_f64(double v, int d) {
     return __hiloint2double(hi, lo);
 }
 
+// Diagnostic build only (-DF2_STAMPS): wave 0 of every workgroup records s_memtime at the phase boundaries.
+#ifdef F2_STAMPS
+#define F2_STAMP(k)                                          \
+    do {                                                     \
+        __builtin_amdgcn_sched_barrier(0);                   \
+        st[k] = __builtin_amdgcn_s_memtime();                \
+        __builtin_amdgcn_sched_barrier(0);                   \
+    } while (0)
+#else
+#define F2_STAMP(k) \
+    do {            \
+    } while (0)
+#endif
+
 struct EnvParams {
     const double* gfb;
     double* env;
@@ -255,6 +294,7 @@ struct EnvParams {
     int C;
     int lpf;
     int f32_in;        // input rows are float32 at the start of their float64 slot (hand-off from K1)
+    unsigned long long* stamps;   // diagnostic build only
     double b0, a1;     // y[n] = b0 (e[n] + e[n-1]) - a1 y[n-1]
 };
 
@@ -276,6 +316,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     constexpr bool KEEP_X = sizeof(F) == 4 && 2 * ITER0 * R0 <= 64;   // x stays in registers for step 5
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     __shared__ double wave_tot[NT / 64];
+    __shared__ F qpow[L];   // (-a1)^(j+1), j < L
     cpx<F>* lds = reinterpret_cast<cpx<F>*>(smem);
     F* rl = reinterpret_cast<F*>(smem);
     const cpx<F>* __restrict__ V = tw + plan_tw_total(LOG2H);   // exp(-2 pi i k / M), k <= H/2
@@ -291,6 +332,10 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     double* __restrict__ y = P.env + row;
     const bool al16 = (row & 1) == 0;   // row start is 16-byte aligned
 
+#ifdef F2_STAMPS
+    unsigned long long st[10] = {0};
+#endif
+    F2_STAMP(0);
     // 1. load: point (i, j) of this thread is m = tid + i*NT + j*NB0
     constexpr bool FULL0 = NB0 % NT == 0;
     cpx<F> v[PT];
@@ -373,44 +418,50 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
             }
         }
     }
+    F2_STAMP(1);
     // 2. forward transform (first pass straight from the registers)
     fft_all<F, LOG2H, false, PT, NT>(lds, tw, tid, v);
-    if constexpr (LOG2H == 0) {
-        if (tid == 0) lds[0] = v[0];
-        __syncthreads();
-    }
-    // 3. packed spectrum of the Hilbert transform, conjugated and scaled by 1/H for step 4
-    {
+    F2_STAMP(2);
+    // 3. packed spectrum of the Hilbert transform, conjugated and scaled by 1/H for step 4:
+    //    W[k] = i sin(t_k) Z[k] + cos(t_k) conj(Z[H-k]), W[0] = 0. Either folded into the first pass of
+    //    step 4 (fuse_hilbert) or one sweep over the pairs (k, H-k) here, all loads issued up front.
+    if constexpr (LOG2H >= 1 && !fuse_hilbert<F, LOG2H>()) {
+        constexpr int NPAIR = H / 2 - 1;                       // pairs (k, H-k), 1 <= k < H/2
+        constexpr int ITERP = (NPAIR + NT - 1) / NT;
         const F sc = F(1.0 / H);
-        for (int k = tid; k <= H / 2; k += NT) {
-            if (k == 0) {
-                lds[cpad(0)] = {F(0), F(0)};
-                continue;
+        if constexpr (NPAIR > 0) {
+            cpx<F> zk[ITERP], zh[ITERP], vk[ITERP];
+#pragma unroll
+            for (int i = 0; i < ITERP; ++i) {
+                const int k = min(1 + tid + i * NT, H / 2 - 1);
+                zk[i] = lds[cpad(k)];
+                zh[i] = lds[cpad(H - k)];
+                vk[i] = V[k];                                   // (cos t, -sin t)
             }
-            const cpx<F> vk = V[k];  // (cos t, -sin t)
-            const F cs = vk.re * sc, sn = -vk.im * sc;
-            const cpx<F> zk = lds[cpad(k)];
-            if (2 * k == H) {
-                // t = pi/2: W = i Z  ->  conj(W) = -i conj(Z) = (-zim, -zre)
-                lds[cpad(k)] = {-zk.im * sc, -zk.re * sc};
-            } else {
-                const cpx<F> zh = lds[cpad(H - k)];
-                // W[k]   = i sn Z[k]   + cs conj(Z[H-k]);  W[H-k] = i sn Z[H-k] - cs conj(Z[k])
-                const cpx<F> wk = {-sn * zk.im + cs * zh.re, sn * zk.re - cs * zh.im};
-                const cpx<F> wh = {-sn * zh.im - cs * zk.re, sn * zh.re + cs * zk.im};
-                lds[cpad(k)] = {wk.re, -wk.im};
-                lds[cpad(H - k)] = {wh.re, -wh.im};
+#pragma unroll
+            for (int i = 0; i < ITERP; ++i) {
+                const int k = 1 + tid + i * NT;
+                const F cs = vk[i].re * sc, sn = -vk[i].im * sc;
+                // W[k] = i sn Z[k] + cs conj(Z[H-k]);  W[H-k] = i sn Z[H-k] - cs conj(Z[k]); stored conjugated
+                if (k < H / 2) {
+                    lds[cpad(k)] = {-sn * zk[i].im + cs * zh[i].re, -(sn * zk[i].re - cs * zh[i].im)};
+                    lds[cpad(H - k)] = {-sn * zh[i].im - cs * zk[i].re, -(sn * zh[i].re + cs * zk[i].im)};
+                }
             }
         }
-    }
-    __syncthreads();
-    // 4. inverse transform (forward transform of the conjugate); outputs stay in v
-    fft_all<F, LOG2H, true, PT, NT>(lds, tw, tid, v);
-    if constexpr (LOG2H == 0) {
-        v[0] = lds[0];
+        if (tid == 0) {
+            const cpx<F> zq = lds[cpad(H / 2)];                 // t = pi/2: W = i Z -> conj(W) = (-zim, -zre)
+            lds[cpad(H / 2)] = {-zq.im * sc, -zq.re * sc};
+            lds[cpad(0)] = {F(0), F(0)};
+        }
         __syncthreads();
     }
+    F2_STAMP(3);
+    // 4. inverse transform (forward transform of the conjugate); outputs stay in v
+    fft_all<F, LOG2H, true, PT, NT>(lds, tw, tid, v);
+    if constexpr (LOG2H == 0) v[0] = {F(0), F(0)};   // H = 1: W[0] = 0, the envelope is |x|
 
+    F2_STAMP(4);
     // 5. magnitude (in F: the FFT already limits the accuracy to F). The last pass left point j of
     //    butterfly i in v[i*R0 + brev(j)]; the envelope pair replaces it there.
 #pragma unroll
@@ -464,6 +515,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
         }
         return;
     }
+    F2_STAMP(5);
     // With the low-pass the envelope goes to LDS, TRANSPOSED: thread t will own the contiguous samples
     // [t*L, (t+1)*L), so sample t*L + j is kept at j*TP + t. (The last FFT pass ended with a barrier after
     // its LDS reads, so the array is free.)
@@ -482,24 +534,56 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     }
     __syncthreads();
 
-    // low-pass: chunked recurrence + multiplicative scan over the 256 chunks
+    F2_STAMP(6);
+    // low-pass: chunked recurrence + multiplicative scan over the chunks. Each thread runs its chunk once
+    // from zero state (float64 accumulator, float32 input term) keeping the zero-state responses; the true
+    // output is that plus carry * (-a1)^(j+1), one float FMA per sample with the powers from an LDS table.
     const int n0 = tid * L;
-    const double b0 = P.b0, na1 = -P.a1;
-    const double eprev = (n0 > 0 && n0 <= n) ? (double)rl[tpos(n0 - 1)] : 0.0;
-    double yz = 0.0;
+    const double na1 = -P.a1;
+    const F b0f = (F)P.b0;
+    const F eprev = (n0 > 0 && n0 <= n) ? rl[tpos(n0 - 1)] : F(0);
+    if (tid < L) {
+        double pw = na1;
+        for (int j = 0; j < tid; ++j) pw *= na1;
+        qpow[tid] = (F)pw;   // (-a1)^(tid+1)
+    }
+    // The chunk is cut into NS sub-chunks whose recurrences run interleaved (independent float64 chains:
+    // the FMA latency is ~25 cycles, a single 32-sample chain would cost more than the arithmetic).
+    constexpr int NS = L >= 16 ? 4 : 1;
+    constexpr int LS = L / NS;
+    F yzs[L];                 // zero-state response of every sub-chunk
+    double zend[NS];
     {
-        double ep = eprev;
-#pragma unroll 8
-        for (int j = 0; j < L; ++j) {
-            const double e = (double)rl[j * TP + tid];   // samples past n hold |0| = 0
-            yz = fma(na1, yz, b0 * (e + ep));
-            ep = e;
+        F ep[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            zend[q] = 0.0;
+            ep[q] = q == 0 ? eprev : rl[(q * LS - 1) * TP + tid];
+        }
+#pragma unroll
+        for (int j = 0; j < LS; ++j) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const F e = rl[(q * LS + j) * TP + tid];   // samples past n hold |0| = 0
+                zend[q] = fma(na1, zend[q], (double)(b0f * (e + ep[q])));
+                yzs[q * LS + j] = (F)zend[q];
+                ep[q] = e;
+            }
         }
     }
-    // g = (-a1)^L
-    double g = na1;
+    // gs = (-a1)^LS, g = (-a1)^L
+    double gs = na1;
 #pragma unroll
-    for (int s = 1; s < L; s <<= 1) g *= g;
+    for (int s2 = 1; s2 < LS; s2 <<= 1) gs *= gs;
+    double g = gs;
+#pragma unroll
+    for (int s2 = 1; s2 < NS; s2 <<= 1) g *= g;
+    // chunk-level zero-state value at the end of every sub-chunk
+    double ysub[NS];
+    ysub[0] = zend[0];
+#pragma unroll
+    for (int q = 1; q < NS; ++q) ysub[q] = fma(gs, ysub[q - 1], zend[q]);
+    const double yz = ysub[NS - 1];
     // inclusive scan inside the wave: v_t = sum_{j<=t} g^(t-j) yz_j
     const int lane = tid & 63, wv = tid >> 6;
     double sc = yz, gd = g;
@@ -510,30 +594,34 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
         gd *= gd;
     }
     // gd == g^64 now
+    F2_STAMP(7);
     if (lane == 63) wave_tot[wv] = sc;
-    __syncthreads();
-    double carry = 0.0;  // true y at the end of the previous wave's last chunk
-    for (int w2 = 0; w2 < wv; ++w2) carry = fma(gd, carry, wave_tot[w2]);
-    // g^(lane+1)
+    // g^(lane+1) (data independent; placed before the barrier to overlap with the other waves' scans)
     double gl = 1.0, gp = g;
     for (int bits = lane + 1; bits; bits >>= 1) {
         if (bits & 1) gl *= gp;
         gp *= gp;
     }
+    __syncthreads();
+    double carry = 0.0;  // true y at the end of the previous wave's last chunk
+    for (int w2 = 0; w2 < wv; ++w2) carry = fma(gd, carry, wave_tot[w2]);
     const double incl = fma(gl, carry, sc);                 // true y at the end of this chunk
     double yprev = shfl_up_f64(incl, 1);                    // ... of the previous chunk
     if (lane == 0) yprev = carry;
     {
-        double ep = eprev, yy = yprev;
-#pragma unroll 8
-        for (int j = 0; j < L; ++j) {
-            const double e = (double)rl[j * TP + tid];
-            yy = fma(na1, yy, b0 * (e + ep));
-            ep = e;
-            rl[j * TP + tid] = (F)yy;
+        // value entering sub-chunk q: chunk-level zero-state part + (-a1)^(q*LS) * yprev
+        double cin = yprev, gq = 1.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const F cq = (F)(q == 0 ? yprev : fma(gq, yprev, ysub[q - 1]));
+            (void)cin;
+#pragma unroll
+            for (int j = 0; j < LS; ++j) rl[(q * LS + j) * TP + tid] = cq * qpow[j] + yzs[q * LS + j];
+            gq *= gs;
         }
     }
     __syncthreads();
+    F2_STAMP(8);
     if (al16) {
 #pragma unroll 4
         for (int i = 2 * tid; i < n; i += 2 * NT) {
@@ -546,6 +634,11 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
 #pragma unroll 4
         for (int i = tid; i < n; i += NT) y[i] = (double)rl[tpos(i)];
     }
+#ifdef F2_STAMPS
+    F2_STAMP(9);
+    if (tid == 0 && P.stamps)
+        for (int k = 0; k < 10; ++k) P.stamps[(size_t)blockIdx.x * 10 + k] = st[k];
+#endif
 }
 
 template <typename F>
@@ -609,6 +702,13 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
              "float32 hand-off needs the float FFT and rows of at most 16384 samples");
     EnvParams P;
     P.f32_in = f32_in ? 1 : 0;
+    P.stamps = nullptr;
+#ifdef F2_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    const size_t nstamp = (size_t)B * C * 10;
+    if (!d_stamps) F2_HIP(ctx, hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 10 * 128 * 2048));
+    if (nstamp <= (size_t)10 * 128 * 2048) P.stamps = d_stamps;
+#endif
     P.gfb = d_gfb;
     P.env = d_env;
     P.offsets = d_offsets;
@@ -672,5 +772,21 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         F2_HIP(ctx, hipGetLastError());
         F2_TRY(f2_prof_end(ctx, F2_K_ENVELOPE));
     }
+#ifdef F2_STAMPS
+    if (P.stamps) {
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<unsigned long long> h(nstamp);
+        F2_HIP(ctx, hipMemcpy(h.data(), d_stamps, sizeof(unsigned long long) * nstamp, hipMemcpyDeviceToHost));
+        double acc[10] = {0};
+        const size_t rows = (size_t)B * C;
+        for (size_t r = 0; r < rows; ++r)
+            for (int k = 1; k < 10; ++k) acc[k] += (double)(h[r * 10 + k] - h[r * 10 + k - 1]);
+        static const char* names[10] = {"", "load", "fwd fft", "hilbert pairs", "inv fft", "magnitude", "transposed write",
+                                        "lpf chunk+scan", "lpf carry+apply", "copy out"};
+        fprintf(stderr, "[stamps] mean cycles per workgroup (s_memtime, 100 MHz ticks x clock):");
+        for (int k = 1; k < 10; ++k) fprintf(stderr, " %s=%.0f", names[k], acc[k] / rows);
+        fprintf(stderr, "\n");
+    }
+#endif
     return F2_OK;
 }

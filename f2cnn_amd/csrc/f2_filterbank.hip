@@ -22,8 +22,8 @@ constexpr int ROWS_PER_STORE = 64 / TB;
 // OutT = double: the (C,N) float64 matrix of the reference. OutT = float: the same row layout but each row's
 // float32 samples sit at the START of that row's float64 slot (row r, sample t -> float index 2*r*N + t), the
 // hand-off format to the float32-FFT envelope kernel, which then overwrites the slot with float64 envelopes.
-// A2ZERO: the numerators have no z^-2 term (always true for make_erb_filters output): 16 float64 ops per
-// sample-channel (the 1/gain factor is folded into the last section's numerator).
+// A2ZERO: the numerators have no z^-2 term (always true for make_erb_filters output): direct form II sections,
+// 13 float64 ops per sample-channel; otherwise the general transposed-direct-form-II recurrences (17 ops).
 template <typename WaveT, typename OutT, bool A2ZERO>
 __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__ wave,
                                                        const int64_t* __restrict__ offsets,
@@ -48,6 +48,9 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
     const double b11 = k[1] * rB0, b12 = k[2] * rB0, b13 = k[3] * rB0;
     // last section scaled by 1/gain: its output is the final sample
     const double b0g = b0 * inv_gain, b14g = k[4] * rB0 * inv_gain, b2g = b2 * inv_gain;
+    // A2ZERO form: zero of section k at -ck, overall factor b0^4 / gain
+    const double c1 = k[1] / k[0], c2 = k[2] / k[0], c3 = k[3] / k[0], c4 = k[4] / k[0];
+    const double scale = (b0 * b0) * (b0 * b0) * inv_gain;
 
     double z10 = 0, z11 = 0, z20 = 0, z21 = 0, z30 = 0, z31 = 0, z40 = 0, z41 = 0;
 
@@ -74,38 +77,76 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
         // out skewed -- step s runs section k on sample s-k+1 -- so that every step holds four independent
         // recurrences and the in-order VALU always has a ready float64 FMA.
         double p1 = 0, p2 = 0, p3 = 0;
+        if constexpr (A2ZERO) {
+            // Numerators T + A1k z^-1 = T (1 + ck z^-1): each section in direct form II costs three FMAs,
+            //   w = in - a1 w[-1] - a2 w[-2] ;  out = w + ck w[-1]
+            // and the factor T^4 / gain is applied once to the last section's output: 13 float64 ops per
+            // sample-channel. (z10/z11 ... hold w[-1]/w[-2] of sections 1..4 in this branch.)
 #pragma unroll
-        for (int s2 = 0; s2 < TB + 3; ++s2) {
-            double n1 = 0, n2 = 0, n3 = 0;
-            if (s2 < TB) {
-                const double x = xs[s2];
-                // y = b0*x + z0 ; z0 = b1*x - a1*y + z1 ; z1 = b2*x - a2*y
-                const double y1 = fma(b0, x, z10);
-                z10 = fma(-a1, y1, fma(b11, x, z11));
-                z11 = A2ZERO ? -a2 * y1 : fma(b2, x, -a2 * y1);
-                n1 = y1;
+            for (int s2 = 0; s2 < TB + 3; ++s2) {
+                double n1 = 0, n2 = 0, n3 = 0;
+                if (s2 < TB) {
+                    const double wv = fma(-a1, z10, fma(-a2, z11, xs[s2]));
+                    n1 = fma(c1, z10, wv);
+                    z11 = z10;
+                    z10 = wv;
+                }
+                if (s2 >= 1 && s2 - 1 < TB) {
+                    const double wv = fma(-a1, z20, fma(-a2, z21, p1));
+                    n2 = fma(c2, z20, wv);
+                    z21 = z20;
+                    z20 = wv;
+                }
+                if (s2 >= 2 && s2 - 2 < TB) {
+                    const double wv = fma(-a1, z30, fma(-a2, z31, p2));
+                    n3 = fma(c3, z30, wv);
+                    z31 = z30;
+                    z30 = wv;
+                }
+                if (s2 >= 3) {
+                    const double wv = fma(-a1, z40, fma(-a2, z41, p3));
+                    tile[lane][s2 - 3] = (OutT)(fma(c4, z40, wv) * scale);
+                    z41 = z40;
+                    z40 = wv;
+                }
+                p1 = n1;
+                p2 = n2;
+                p3 = n3;
             }
-            if (s2 >= 1 && s2 - 1 < TB) {
-                const double y2 = fma(b0, p1, z20);
-                z20 = fma(-a1, y2, fma(b12, p1, z21));
-                z21 = A2ZERO ? -a2 * y2 : fma(b2, p1, -a2 * y2);
-                n2 = y2;
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < TB + 3; ++s2) {
+                double n1 = 0, n2 = 0, n3 = 0;
+                if (s2 < TB) {
+                    const double x = xs[s2];
+                    // transposed direct form II: y = b0*x + z0 ; z0 = b1*x - a1*y + z1 ; z1 = b2*x - a2*y
+                    const double y1 = fma(b0, x, z10);
+                    z10 = fma(-a1, y1, fma(b11, x, z11));
+                    z11 = fma(b2, x, -a2 * y1);
+                    n1 = y1;
+                }
+                if (s2 >= 1 && s2 - 1 < TB) {
+                    const double y2 = fma(b0, p1, z20);
+                    z20 = fma(-a1, y2, fma(b12, p1, z21));
+                    z21 = fma(b2, p1, -a2 * y2);
+                    n2 = y2;
+                }
+                if (s2 >= 2 && s2 - 2 < TB) {
+                    const double y3 = fma(b0, p2, z30);
+                    z30 = fma(-a1, y3, fma(b13, p2, z31));
+                    z31 = fma(b2, p2, -a2 * y3);
+                    n3 = y3;
+                }
+                if (s2 >= 3) {
+                    const double y4 = fma(b0g, p3, z40);
+                    z40 = fma(-a1, y4, fma(b14g, p3, z41));
+                    z41 = fma(b2g, p3, -a2 * y4);
+                    tile[lane][s2 - 3] = (OutT)y4;
+                }
+                p1 = n1;
+                p2 = n2;
+                p3 = n3;
             }
-            if (s2 >= 2 && s2 - 2 < TB) {
-                const double y3 = fma(b0, p2, z30);
-                z30 = fma(-a1, y3, fma(b13, p2, z31));
-                z31 = A2ZERO ? -a2 * y3 : fma(b2, p2, -a2 * y3);
-                n3 = y3;
-            }
-            if (s2 >= 3) {
-                const double y4 = fma(b0g, p3, z40);
-                z40 = fma(-a1, y4, fma(b14g, p3, z41));
-                z41 = A2ZERO ? -a2 * y4 : fma(b2g, p3, -a2 * y4);
-                tile[lane][s2 - 3] = (OutT)y4;
-            }
-            p1 = n1;
-            p2 = n2;
-            p3 = n3;
         }
         __syncthreads();
         if (fits32 && full_rows && t0 + TB <= N) {
