@@ -133,6 +133,9 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     for (auto& prec : ctx->tw)
         for (f2_scratch& s : prec)
             if (s.ptr) (void)hipFree(s.ptr);
+    for (auto& prec : ctx->tw_large)
+        for (f2_scratch& s : prec)
+            if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -30,7 +30,9 @@
 // Bound: HBM, 16 bytes per sample-channel (8 read + 8 written).
 #include <cmath>
 
-#include "f2_internal.h"
+#include "f2_envelope_core.h"
+
+using namespace f2fft;
 
 namespace {
 
@@ -41,83 +43,6 @@ constexpr int threads_for() { return LOG2H >= 13 ? 512 : 256; }
 template <typename F, int LOG2H>
 constexpr int min_waves_for() {
     return (sizeof(F) == 4 && LOG2H == 13) ? 4 : (sizeof(F) == 4 && LOG2H <= 12) ? 2 : (sizeof(F) == 8 && LOG2H <= 12) ? 2 : 2;
-}
-
-template <typename F>
-struct cpx {
-    F re, im;
-};
-template <typename F>
-__device__ __forceinline__ cpx<F> operator+(cpx<F> a, cpx<F> b) { return {a.re + b.re, a.im + b.im}; }
-template <typename F>
-__device__ __forceinline__ cpx<F> operator-(cpx<F> a, cpx<F> b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ float fsqrt(float v) { return __builtin_amdgcn_sqrtf(v); }   // v_sqrt_f32, 1 ulp
-__device__ __forceinline__ double fsqrt(double v) { return sqrt(v); }
-template <typename F>
-__device__ __forceinline__ cpx<F> cmul(cpx<F> a, cpx<F> w) {
-    return {a.re * w.re - a.im * w.im, a.re * w.im + a.im * w.re};
-}
-
-// cos/sin(2 pi j / 32), j = 0..15
-__device__ constexpr double kCos32[16] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
-                                          0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
-                                          0.19509032201612826785, 0.0, -0.19509032201612826785, -0.38268343236508977173,
-                                          -0.55557023301960222474, -0.70710678118654752440, -0.83146961230254523708,
-                                          -0.92387953251128675613, -0.98078528040323044913};
-__device__ constexpr double kSin32[16] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
-                                          0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613,
-                                          0.98078528040323044913, 1.0, 0.98078528040323044913, 0.92387953251128675613,
-                                          0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474,
-                                          0.38268343236508977173, 0.19509032201612826785};
-
-// a * exp(-2 pi i K / R)
-template <int R, int K, typename F>
-__device__ __forceinline__ cpx<F> mulw(cpx<F> a) {
-    if constexpr (K == 0) {
-        return a;
-    } else if constexpr (4 * K == R) {
-        return {a.im, -a.re};
-    } else if constexpr (8 * K == R) {
-        const F h = F(0.70710678118654752440);
-        return {(a.re + a.im) * h, (a.im - a.re) * h};
-    } else if constexpr (8 * K == 3 * R) {
-        const F h = F(0.70710678118654752440);
-        return {(a.im - a.re) * h, -(a.re + a.im) * h};
-    } else {
-        const F c = F(kCos32[K * 32 / R]), s = F(kSin32[K * 32 / R]);
-        return {a.re * c + a.im * s, a.im * c - a.re * s};
-    }
-}
-
-template <int R, int J, typename F>
-__device__ __forceinline__ void dif_stage(cpx<F>* v) {
-    if constexpr (J < R / 2) {
-        const cpx<F> a = v[J], b = v[J + R / 2];
-        v[J] = a + b;
-        v[J + R / 2] = mulw<R, J>(a - b);
-        dif_stage<R, J + 1>(v);
-    }
-}
-
-// forward DFT of R points held in registers, decimation in frequency, in place (no register shuffling):
-// natural order in, BIT-REVERSED order out: X[k] is left in v[brev<R>(k)]
-template <int R, typename F>
-__device__ __forceinline__ void dft(cpx<F>* v) {
-    if constexpr (R >= 2) {
-        dif_stage<R, 0>(v);
-        dft<R / 2>(v);
-        dft<R / 2>(v + R / 2);
-    }
-}
-
-template <int R>
-constexpr int brev(int k) {
-    int r = 0;
-    for (int b = 1; b < R; b <<= 1) {
-        r = (r << 1) | (k & 1);
-        k >>= 1;
-    }
-    return r;
 }
 
 // Whether the Hilbert pair step is folded into the inverse transform's first pass (needs ~3x the pass's points in
@@ -263,13 +188,6 @@ __device__ __forceinline__ void fft_all(cpx<F>* lds, const cpx<F>* __restrict__ 
         fft_pass<F, LOG2H, PASS, SRC, DST, PTV, NT, INVERSE && PASS == 0 && fuse_hilbert<F, LOG2H>()>(lds, tw, tid, v);
         fft_all<F, LOG2H, INVERSE, PTV, NT, PASS + 1>(lds, tw, tid, v);
     }
-}
-
-__device__ __forceinline__ double shfl_up_f64(double v, int d) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_up(lo, d);
-    hi = __shfl_up(hi, d);
-    return __hiloint2double(hi, lo);
 }
 
 // Diagnostic build only (-DF2_STAMPS): wave 0 of every workgroup records s_memtime at the phase boundaries.
@@ -721,15 +639,23 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
 
     // group the utterances by padded length (one kernel instantiation per FFT size)
     std::vector<std::vector<int>> groups(32);
+    int n_large = 0;
     for (int b = 0; b < B; ++b) {
         const int64_t n = h_offsets[b + 1] - h_offsets[b];
         if (n <= 0) continue;
         const int log2m = n <= 2 ? 1 : f2_log2_ceil(n);
         const int log2h = log2m - 1;
         const int maxl = precision == F2_FFT_F32 ? MAX_LOG2H_F32 : MAX_LOG2H_F64;
-        F2_CHECK(ctx, log2h <= maxl, F2_ERR_UNSUPPORTED,
-                 "utterance %d has %lld samples; rows longer than %d samples are not supported with this FFT precision",
-                 b, (long long)n, 2 << maxl);
+        if (log2h > maxl) {
+            // longer than the LDS-resident transform: global-memory path, one utterance at a time
+            F2_CHECK(ctx, !f32_in, F2_ERR_INVALID, "float32 hand-off is not available for long rows");
+            F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
+            F2_TRY(f2_launch_envelope_large(ctx, d_gfb + (size_t)C * (size_t)h_offsets[b],
+                                            d_env + (size_t)C * (size_t)h_offsets[b], n, C, P.lpf, P.b0, P.a1, precision));
+            F2_TRY(f2_prof_end(ctx, F2_K_ENVELOPE));
+            ++n_large;
+            continue;
+        }
         groups[log2h].push_back(b);
     }
     size_t list_elems = 0;
@@ -739,7 +665,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
             ++ngroups;
             list_elems += g.size();
         }
-    const bool identity = ngroups == 1 && (int)list_elems == B;
+    const bool identity = ngroups == 1 && (int)list_elems == B && n_large == 0;
     int* d_lists = nullptr;
     if (!identity && ngroups > 0) {
         std::vector<int> flat;

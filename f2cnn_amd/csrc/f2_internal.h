@@ -33,6 +33,7 @@ struct f2_ctx {
     f2_scratch work2;
     f2_scratch xbuf;       // window tensor chunk between K3 and K4
     f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
+    f2_scratch tw_large[2][24];   // same for the global-memory transform of long rows
     std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
     std::vector<double> coefs_host;     // what ctx->coefs currently holds
     bool prof_on = false;
@@ -82,6 +83,11 @@ int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C);
 // RAII-free profiling bracket: F2_PROF_BEGIN before the launch(es) of one kernel id, F2_PROF_END after.
 int f2_prof_begin(f2_ctx* ctx, int kernel_id);
 int f2_prof_end(f2_ctx* ctx, int kernel_id);
+
+// longest row (2^22 samples = 262 s at 16 kHz) the global-memory envelope path accepts
+#define F2_MAX_LOG2M_LARGE 22
+int f2_launch_envelope_large(f2_ctx* ctx, const double* d_x, double* d_y, int64_t n, int C, int lpf, double b0,
+                             double a1, int precision);
 
 static inline int f2_log2_ceil(int64_t n) {
     int k = 0;

@@ -49,10 +49,24 @@ def test_fft32_longest_rows(N):
         assert chan_relerr(EE.ExtractEnvelopeFromMatrix(m, lpf, 50, precision=_lib.FFT_F32), ref) <= TOL
 
 
-def test_too_long_is_reported_not_wrong():
-    with pytest.raises(_lib.F2Error) as e:
-        EE.ExtractEnvelopeFromMatrix(np.ones((1, 40000)), False, precision=_lib.FFT_F32)
-    assert e.value.code == _lib.F2_ERR_UNSUPPORTED
+@pytest.mark.parametrize("N,precision,tol", [(40000, _lib.FFT_F32, TOL), (48000, _lib.FFT_F32, TOL), (65536, _lib.FFT_F32, TOL),
+                                             (70001, _lib.FFT_F32, TOL), (20000, _lib.FFT_F64, TOL_F64),
+                                             (50000, _lib.FFT_F64, TOL_F64)])
+def test_long_rows_global_memory_path(N, precision, tol):
+    # TIMIT sentences are 1-8 s: rows beyond the LDS-resident transform take the global-memory path
+    m = np.random.default_rng(N).standard_normal((3, N)) * np.array([[1.0], [3000.0], [1e-3]])
+    for lpf in (False, True):
+        ref = orc.extract_envelope_from_matrix(m, lpf, 50)
+        got = EE.ExtractEnvelopeFromMatrix(m, lpf, 50, precision=precision)
+        assert chan_relerr(got, ref) <= tol, (N, lpf)
+
+
+def test_mixed_short_and_long_batch():
+    rng = np.random.default_rng(77)
+    mats = [rng.standard_normal((4, n)) for n in (16000, 50000, 1000, 33000)]
+    outs = EE.ExtractEnvelopesFromMatrices(mats, True, 50)
+    for m, o in zip(mats, outs):
+        assert chan_relerr(o, orc.extract_envelope_from_matrix(m, True, 50)) <= TOL
 
 
 def test_on_filterbank_output_cfg1():

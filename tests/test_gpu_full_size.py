@@ -1,0 +1,79 @@
+"""BASELINE-sized runs on the GPU (device buffers through the C ABI), checked through size-independent properties
+and spot rows against the oracle: cfg2 (256 x 1 s, 128 channels, filterbank) and a 256-utterance slice of cfg3."""
+import numpy as np
+import pytest
+
+import bench
+import f2cnn_oracle as orc
+from conftest import chan_relerr
+from f2cnn_amd import _lib
+from f2cnn_amd.gammatone import filters
+
+pytestmark = pytest.mark.gpu
+B, C, N = 256, 128, 16000
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
+    waves = bench.synth_batch(2026, 0, B, N)
+    off = np.arange(B + 1, dtype=np.int64) * N
+    d_wave = ctx.malloc(waves.nbytes)
+    ctx.h2d(d_wave, waves)
+    yield ctx, coefs, waves, off, d_wave
+    ctx.free(d_wave)
+
+
+def fetch_rows(ctx, dptr, b, rows):
+    out = np.empty((len(rows), N))
+    for i, c in enumerate(rows):
+        ctx.d2h(out[i], dptr + 8 * ((b * C + c) * N))
+    return out
+
+
+def test_cfg2_filterbank_full_batch(corpus):
+    ctx, coefs, waves, off, d_wave = corpus
+    d_gfb = ctx.malloc(8 * B * C * N)
+    ctx.memset(d_gfb, 0xFF, 8 * B * C * N)          # NaN pattern: every element must be overwritten
+    ctx.erb_filterbank_batch(d_wave, _lib.WAVE_I16, off, coefs, B, C, d_gfb, _lib.MEM_DEVICE)
+    ctx.synchronize()
+    rows = [0, 1, 63, 64, 126, 127]
+    for b in (0, 100, 255):
+        got = fetch_rows(ctx, d_gfb, b, rows)
+        assert chan_relerr(got, orc.erb_filterbank(waves[b], coefs[rows])) <= 1e-9
+    # batching must not matter: utterance 255 alone gives the same bits as inside the batch
+    alone = filters.erb_filterbank(waves[255], coefs)
+    np.testing.assert_array_equal(alone[rows], fetch_rows(ctx, d_gfb, 255, rows))
+    # no element left untouched anywhere in the 4.2 GB output (sum of a checksum per utterance is finite)
+    whole = np.empty((C, N))
+    sums = []
+    for b in range(0, B, 17):
+        ctx.d2h(whole, d_gfb + 8 * b * C * N)
+        assert np.isfinite(whole).all()
+        sums.append(float(np.abs(whole).sum()))
+    assert np.isfinite(sum(sums)) and min(sums) > 0
+    ctx.free(d_gfb)
+
+
+def test_cfg3_fused_slice_matches_two_step_and_oracle(corpus):
+    ctx, coefs, waves, off, d_wave = corpus
+    d_env = ctx.malloc(8 * B * C * N)
+    d_ref = ctx.malloc(8 * B * C * N)
+    ctx.filterbank_envelope_fused(d_wave, _lib.WAVE_I16, off, coefs, B, C, True, 50.0, _lib.FFT_F32, d_env, None,
+                                  _lib.MEM_DEVICE)
+    # the same through the two public steps with the float64 hand-off
+    ctx.erb_filterbank_batch(d_wave, _lib.WAVE_I16, off, coefs, B, C, d_ref, _lib.MEM_DEVICE)
+    ctx.envelope_batch(d_ref, off, B, C, True, 50.0, _lib.FFT_F32, d_ref, _lib.MEM_DEVICE)
+    ctx.synchronize()
+    rows = [0, 31, 64, 127]
+    for b in (0, 77, 255):
+        fused = fetch_rows(ctx, d_env, b, rows)
+        two = fetch_rows(ctx, d_ref, b, rows)
+        ref = orc.extract_envelope_from_matrix(orc.erb_filterbank(waves[b], coefs[rows]), True, 50)
+        assert chan_relerr(fused, ref) <= 1e-5
+        assert chan_relerr(two, ref) <= 1e-5
+        assert chan_relerr(fused, two) <= 2e-6      # float32 vs float64 hand-off
+        assert (fused > 0).all()                    # envelopes of noise are strictly positive (normalizeInput needs it)
+    ctx.free(d_env)
+    ctx.free(d_ref)

@@ -138,3 +138,17 @@ def test_eval_pipeline_cfg4_shape(tmp_path, monkeypatch):
     # too short for a single window: no scores, no error
     s2, l2 = Evaluating.EvaluateOneWavArray(wave[:1700], 16000, model=m)
     assert s2.shape == (0, 2) and l2.shape == (0,)
+
+
+def test_eval_pipeline_long_utterance(tmp_path, monkeypatch):
+    # a 2.5 s utterance goes through the long-row envelope path inside f2_eval_utterance
+    monkeypatch.chdir(tmp_path)
+    wave = orc.synth_utterance(7, 40000)
+    m = F2CNNModel.glorot(3)
+    scores, labels, env = Evaluating.EvaluateOneWavArray(wave, 16000, model=m, LPF=False, return_envelopes=True)
+    coefs = orc.make_erb_filters(16000, orc.centre_freqs(16000, 128, 100))
+    assert chan_relerr(env, orc.filter_and_envelope(wave, coefs, False)) <= 1e-5
+    assert scores.shape == (40000 - 1760, 2)
+    np.testing.assert_array_equal(labels, (scores[:, 1] > scores[:, 0]).astype(np.uint8))
+    ref = orc.cnn_forward(orc.eval_input_tensor(env)[::97], oracle_weights(m))
+    np.testing.assert_allclose(scores[::97], ref, atol=5e-4)
