@@ -90,10 +90,12 @@ template <int CIN, int COUT, bool SAME, bool POOL, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __restrict__ in, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              int Hin, int Win, int64_t nwin) {
-    constexpr int PS = CIN + 1;           // LDS pitch per pixel
+    constexpr int PS = CIN + 4;           // LDS pitch per pixel: 16-byte aligned and conflict-free for ds_read_b128
     constexpr int PATCH = 4 * PW * PS;    // floats per wave
     constexpr int NT = COUT / 32;
     constexpr int PAD = SAME ? 1 : 0;
+    constexpr int C4 = CIN / 4;           // float4 per pixel
+    constexpr int HALF = CIN / 2;         // MFMA k = 0 takes channel s, k = 1 takes channel HALF + s
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,16 +116,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     const int64_t win = t2 / row_pairs;
     const int y0 = 2 * rp, x0 = 32 * xt;
 
-    // stage the 4 x 34 x CIN patch (zero outside the image: 'same' padding and tile overhang)
+    // stage the 4 x 34 x CIN patch with 16-byte loads (zero outside the image: 'same' padding / tile overhang)
     const float* img = in + win * (int64_t)Hin * Win * CIN;
-    for (int e = lane; e < 4 * PW * CIN; e += 64) {
-        const int r = e / (PW * CIN);
-        const int rem = e - r * (PW * CIN);
-        const int p = rem / CIN, ci = rem - p * CIN;
+#pragma unroll 4
+    for (int e = lane; e < 4 * PW * C4; e += 64) {
+        const int r = e / (PW * C4);
+        const int rem = e - r * (PW * C4);
+        const int p = rem / C4, c4 = rem - p * C4;
         const int yi = y0 - PAD + r, xi = x0 - PAD + p;
-        float v = 0.f;
-        if (yi >= 0 && yi < Hin && xi >= 0 && xi < Win) v = img[((int64_t)yi * Win + xi) * CIN + ci];
-        patch[(r * PW + p) * PS + ci] = v;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
+            v = *reinterpret_cast<const float4*>(img + ((int64_t)yi * Win + xi) * CIN + c4 * 4);
+        *reinterpret_cast<float4*>(patch + (r * PW + p) * PS + c4 * 4) = v;
     }
     __syncthreads();
 
@@ -135,21 +139,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[rr][nt][q] = 0.f;
 
+    // lane = (pixel i, half h). Step s of a tap multiplies channels s (h = 0) and HALF + s (h = 1): four
+    // consecutive steps are one float4 of the patch (A) and one float4 of the re-laid-out weights (B),
+    // wt[tap][h][s/4][cout][s%4].
     const int i = lane & 31, h = lane >> 5;
+    const float* pa0 = patch + i * PS + h * HALF;
+    const float4* wq = reinterpret_cast<const float4*>(w) + (int64_t)h * (HALF / 4) * COUT + i;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
-        const float* pa = patch + ((dy * PW) + i + dx) * PS + h;
-        const float* pb = w + ((int64_t)(tap * CIN + h) * COUT) + i;
-#pragma unroll 8
-        for (int ci = 0; ci < CIN; ci += 2) {
-            const float a0 = pa[ci];
-            const float a1 = pa[PW * PS + ci];
+        const float* pa = pa0 + (dy * PW + dx) * PS;
+        const float4* pb = wq + (int64_t)tap * 2 * (HALF / 4) * COUT;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float b = pb[(int64_t)ci * COUT + nt * 32];
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][nt], 0, 0, 0);
+        for (int q = 0; q < HALF / 4; ++q) {
+            const float4 a0 = *reinterpret_cast<const float4*>(pa + 4 * q);
+            const float4 a1 = *reinterpret_cast<const float4*>(pa + PW * PS + 4 * q);
+            float4 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = pb[(int64_t)q * COUT + nt * 32];
+            const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float bv = r == 0 ? b[nt].x : r == 1 ? b[nt].y : r == 2 ? b[nt].z : b[nt].w;
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[r], bv, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[r], bv, acc[1][nt], 0, 0, 0);
+                }
             }
         }
     }
@@ -251,7 +267,7 @@ int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, fl
     const int xtiles = (wneed + 31) / 32;
     const int64_t tasks = n * row_pairs * xtiles;
     if (tasks <= 0) return F2_OK;
-    constexpr size_t lds = sizeof(float) * WAVES * 4 * PW * (CIN + 1);
+    constexpr size_t lds = sizeof(float) * WAVES * 4 * PW * (CIN + 4);
     auto kern = k_conv3x3_mfma<CIN, COUT, SAME, POOL, WAVES>;
     if (lds > 64 * 1024)
         F2_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -327,8 +343,24 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
         delete cnn;
         return f2_fail(ctx, F2_ERR_NOMEM, "hipMalloc(%zu) -> %s", total * sizeof(float), hipGetErrorString(e));
     }
+    // conv2..conv4 kernels are stored as the MFMA B operand wt[tap][h][s/4][cout][s%4] (channel = h*Cin/2 + s);
+    // everything else stays in its Keras layout
+    std::vector<std::vector<float>> relaid(12);
+    const int conv_cin[3] = {C1, C2, C3}, conv_cout[3] = {C2, C3, C4};
+    for (int l = 0; l < 3; ++l) {
+        const int ti = 2 + 2 * l, ci_n = conv_cin[l], co_n = conv_cout[l], half = ci_n / 2;
+        std::vector<float>& dst = relaid[ti];
+        dst.resize(sizes[ti]);
+        for (int tap = 0; tap < 9; ++tap)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int sidx = 0; sidx < half; ++sidx)
+                    for (int co = 0; co < co_n; ++co)
+                        dst[((((size_t)tap * 2 + hh) * (half / 4) + sidx / 4) * co_n + co) * 4 + sidx % 4] =
+                            tensors[ti][((size_t)tap * ci_n + hh * half + sidx) * co_n + co];
+    }
     for (int i = 0; i < 12; ++i) {
-        e = hipMemcpyAsync(cnn->blob + cnn->off[i], tensors[i], sizes[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        const float* src = relaid[i].empty() ? tensors[i] : relaid[i].data();
+        e = hipMemcpyAsync(cnn->blob + cnn->off[i], src, sizes[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) break;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
