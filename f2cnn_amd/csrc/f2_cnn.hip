@@ -197,39 +197,80 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     }
 }
 
-// ---- dense1: (n, K) x (K, 516) on the same MFMA; one wave = 32 windows x 32 outputs ----
-__global__ __launch_bounds__(256) void k_dense1_mfma(const float* __restrict__ a, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, float* __restrict__ out, int K,
-                                                     int64_t n) {
-    constexpr int NTILES = (D1 + 31) / 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t mtiles = (n + 31) / 32;
-    if (task >= mtiles * NTILES) return;
-    const int nt = (int)(task % NTILES);
-    const int64_t w0 = (task / NTILES) * 32;
+// ---- dense1: (n, K) x (K, 516) on the same MFMA ----
+// One 6-wave workgroup = 32 windows x all 17 output tiles (wave w owns tiles w, w+6, w+12). K is walked in
+// chunks of 64: the 32 x 64 activation chunk is staged in LDS (double buffered, 16-byte loads, pitch 68) and
+// read back as the A operand with ds_read_b128; the B operand comes from the re-laid-out weights
+// wt[chunk][h][q][n (padded to 544)][4], one 16-byte load per four MFMA steps.
+constexpr int D1_TILES = (D1 + 31) / 32;   // 17
+constexpr int D1_NPAD = D1_TILES * 32;     // 544
+constexpr int D1_KC = 64;
+constexpr int D1_WAVES = 6;
+__global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __restrict__ a, const float* __restrict__ wt,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int K, int64_t n) {
+    constexpr int PS = D1_KC + 4;
+    constexpr int TPW = (D1_TILES + D1_WAVES - 1) / D1_WAVES;   // tiles per wave (3)
+    __shared__ __attribute__((aligned(16))) float As[2][32 * PS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * 32;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t wi = w0 + i < n ? w0 + i : n - 1;
-    const int col = nt * 32 + i;
-    const bool colok = col < D1;
-    const float* pa = a + wi * K + h;
-    const float* pb = w + (int64_t)h * D1 + (colok ? col : 0);
-    f32x16 acc;
+    const int nchunks = K / D1_KC;
+
+    auto stage = [&](int kc, int buf) {
+        for (int e = tid; e < 32 * (D1_KC / 4); e += D1_WAVES * 64) {
+            const int row = e / (D1_KC / 4), c4 = e - row * (D1_KC / 4);
+            const int64_t wr = w0 + row < n ? w0 + row : n - 1;
+            *reinterpret_cast<float4*>(&As[buf][row * PS + c4 * 4]) =
+                *reinterpret_cast<const float4*>(a + wr * K + (int64_t)kc * D1_KC + c4 * 4);
+        }
+    };
+
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < K; k += 2) {
-        const float av = pa[k];
-        float bv = pb[(int64_t)k * D1];
-        if (!colok) bv = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) stage(kc + 1, buf ^ 1);
+        const float* pa = &As[buf][i * PS + h * (D1_KC / 2)];
+        const float4* pb = reinterpret_cast<const float4*>(wt) + ((int64_t)(kc * 2 + h) * (D1_KC / 8)) * D1_NPAD + i;
+#pragma unroll
+        for (int q = 0; q < D1_KC / 8; ++q) {
+            const float4 av = *reinterpret_cast<const float4*>(pa + 4 * q);
+            const float avv[4] = {av.x, av.y, av.z, av.w};
+            float4 bv[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int nt = wave + t * D1_WAVES;
+                bv[t] = nt < D1_TILES ? pb[(int64_t)q * D1_NPAD + nt * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const float b = r == 0 ? bv[t].x : r == 1 ? bv[t].y : r == 2 ? bv[t].z : bv[t].w;
+                    if (wave + t * D1_WAVES < D1_TILES) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[r], b, acc[t], 0, 0, 0);
+                }
+        }
+        __syncthreads();
     }
-    if (!colok) return;
-    const float b = bias[col];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int64_t wr = w0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (wr < n) out[wr * D1 + col] = fmaxf(acc[q] + b, 0.f);
+    for (int t = 0; t < TPW; ++t) {
+        const int nt = wave + t * D1_WAVES;
+        const int col = nt * 32 + i;
+        if (nt < D1_TILES && col < D1) {
+            const float b = bias[col];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t wr = w0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (wr < n) out[wr * D1 + col] = fmaxf(acc[t][q] + b, 0.f);
+            }
+        }
     }
 }
 
@@ -303,8 +344,7 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
     F2_TRY((launch_conv<C2, C3, true, false, 4>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
     F2_TRY((launch_conv<C3, C4, false, true, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
     {
-        const int64_t tasks = ((n + 31) / 32) * ((D1 + 31) / 32);
-        hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, ctx->stream, a4, cnn->t(8),
+        hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((n + 31) / 32)), dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8),
                            cnn->t(9), a5, d.flat, n);
         F2_HIP(ctx, hipGetLastError());
     }
@@ -327,6 +367,9 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
     const size_t sizes[12] = {9 * C1, C1, 9 * (size_t)C1 * C2, C2, 9 * (size_t)C2 * C3, C3, 9 * (size_t)C3 * C4, C4,
                               (size_t)d.flat * D1, D1, (size_t)D1 * D2, D2};
     for (int i = 0; i < 12; ++i) F2_CHECK(ctx, tensors[i], F2_ERR_INVALID, "weight tensor %d is NULL", i);
+    size_t dev_sizes[12];
+    for (int i = 0; i < 12; ++i) dev_sizes[i] = sizes[i];
+    dev_sizes[8] = (size_t)d.flat * D1_NPAD;   // dense1 kernel, output dimension padded to whole MFMA tiles
     F2_HIP(ctx, hipSetDevice(ctx->device));
     f2_cnn* cnn = new f2_cnn();
     cnn->rows = rows;
@@ -336,7 +379,7 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
     size_t total = 0;
     for (int i = 0; i < 12; ++i) {
         cnn->off[i] = total;
-        total += (sizes[i] + 63) & ~size_t(63);   // keep every tensor 256-byte aligned
+        total += (dev_sizes[i] + 63) & ~size_t(63);   // keep every tensor 256-byte aligned
     }
     hipError_t e = hipMalloc((void**)&cnn->blob, total * sizeof(float));
     if (e != hipSuccess) {
@@ -358,9 +401,20 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
                         dst[((((size_t)tap * 2 + hh) * (half / 4) + sidx / 4) * co_n + co) * 4 + sidx % 4] =
                             tensors[ti][((size_t)tap * ci_n + hh * half + sidx) * co_n + co];
     }
+    {
+        // dense1 kernel as wt[chunk][h][q][n][4]: k = chunk*64 + h*32 + q*4 + r, zero columns for n >= 516
+        std::vector<float>& dst = relaid[8];
+        dst.assign(dev_sizes[8], 0.f);
+        for (int k = 0; k < d.flat; ++k) {
+            const int kc = k / D1_KC, kk = k % D1_KC, hh = kk / (D1_KC / 2), sidx = kk % (D1_KC / 2);
+            for (int nn = 0; nn < D1; ++nn)
+                dst[((((size_t)kc * 2 + hh) * (D1_KC / 8) + sidx / 4) * D1_NPAD + nn) * 4 + sidx % 4] =
+                    tensors[8][(size_t)k * D1 + nn];
+        }
+    }
     for (int i = 0; i < 12; ++i) {
         const float* src = relaid[i].empty() ? tensors[i] : relaid[i].data();
-        e = hipMemcpyAsync(cnn->blob + cnn->off[i], src, sizes[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(cnn->blob + cnn->off[i], src, dev_sizes[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) break;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
