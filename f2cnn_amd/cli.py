@@ -5,6 +5,8 @@ package implements:
     python -m f2cnn_amd prepare envelope [--cutoff/-c HZ]
     python -m f2cnn_amd prepare input [--cutoff HZ] [--label/-l CSV] [--input/-i NPY]
     python -m f2cnn_amd cnn eval --file/-f WAV [--lpf HZ] [--model/-m NPZ]
+    python -m f2cnn_amd cnn evalnoise --file/-f WAV --noise/-n SNRdB [--lpf HZ] [--model/-m NPZ]
+    python -m f2cnn_amd cnn evalrand [--count/-c N] [--lpf HZ] [--model/-m NPZ]
     python -m f2cnn_amd --configure            (writes configF2CNN.conf with the reference's defaults)
 
 organize / label / train / plot need the licensed TIMIT+VTR corpora or Keras and stay with the reference.
@@ -12,7 +14,7 @@ organize / label / train / plot need the licensed TIMIT+VTR corpora or Keras and
 import argparse
 
 PREPARE = ("filter", "envelope", "input")
-CNN = ("eval",)
+CNN = ("eval", "evalnoise", "evalrand")
 
 
 def build_parser():
@@ -31,6 +33,8 @@ def build_parser():
     c.add_argument('--model', '-m', dest='model', nargs='?')
     c.add_argument('cnn_command', choices=CNN)
     c.add_argument('--lpf', action='store', type=int, dest='CUTOFF', help="low pass filter the envelopes")
+    c.add_argument('--count', '-c', action='store', type=int, help="number of files to evaluate (evalrand)")
+    c.add_argument('--noise', '-n', action='store', type=float, dest='SNRdB', help="SNR in dB (evalnoise)")
     return parser
 
 
@@ -54,17 +58,28 @@ def main(argv=None):
             from .scripts.processing.InputGenerator import GenerateInputData as fn
         fn(**kwargs)
     elif 'cnn_command' in args:
-        if args.file is None:
-            print("Please use --file or -f to give input file")
-            return 1
-        from .scripts.CNN.Evaluating import EvaluateOneWavFile
-        kwargs = {'file': args.file}
+        from .scripts.CNN import Evaluating
+        kwargs = {}
         if args.CUTOFF is not None:                            # f2cnn.py:149-151
             kwargs['LPF'] = True
             kwargs['CUTOFF'] = args.CUTOFF
         if args.model is not None:
             kwargs['model'] = args.model
-        EvaluateOneWavFile(**kwargs)
+        if args.cnn_command == 'evalrand':                     # needs no --file (unreachable in the reference CLI)
+            if args.count is not None:
+                kwargs['count'] = args.count
+            Evaluating.EvaluateRandom(**kwargs)
+            return 0
+        if args.file is None:
+            print("Please use --file or -f to give input file")
+            return 1
+        kwargs['file'] = args.file
+        if args.cnn_command == 'evalnoise':
+            if args.SNRdB is not None:
+                kwargs['SNRdB'] = args.SNRdB
+            Evaluating.EvaluateWithNoise(**kwargs)
+        else:
+            Evaluating.EvaluateOneWavFile(**kwargs)
     elif args.configure:
         from .config import write_default
         print("Saving configuration file as '{}'".format(write_default()))

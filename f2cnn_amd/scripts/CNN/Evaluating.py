@@ -68,3 +68,78 @@ def EvaluateOneWavFile(file, LPF=False, CUTOFF=50, model='last_trained_model', C
     print("\t\t{}\tdone ! {} windows: {} rising, {} falling -> {}".format(file, len(labels), rising,
                                                                           len(labels) - rising, out))
     return scores, labels
+
+
+# ---- batch / noise evaluation (reference scripts/CNN/Evaluating.py:138-221) -------------
+def EvaluateRandom(count=None, LPF=False, CUTOFF=50, model='last_trained_model'):
+    """`cnn evalrand`: evaluate the WAV files under resources/f2cnn/*/ in random order (all of them, or `count`
+    drawn with replacement like numpy.random.choice in the reference). The filterbank is designed once and the model
+    is uploaded once (the reference reloads the Keras model for every file)."""
+    import glob
+    import time
+    TotalTime = time.time()
+    wavFiles = sorted(glob.glob(os.path.join('resources', 'f2cnn', '*', '*.WAV')))
+    if not wavFiles:
+        print("NO WAV FILES FOUND")
+        exit(-1)
+    print("\n###############################\nEvaluating network on {} WAV files in '{}'.".format(
+        len(wavFiles), os.path.split(wavFiles[0])[0]))
+    cfg = F2Config()
+    CENTER_FREQUENCIES = filters.centre_freqs(cfg.framerate, cfg.nchannels, cfg.low_freq)
+    FILTERBANK_COEFFICIENTS = filters.make_erb_filters(cfg.framerate, CENTER_FREQUENCIES)
+    if not isinstance(model, F2CNNModel):
+        model = load_model(model)
+    if count is None:
+        wavFiles = list(numpy.random.permutation(wavFiles))
+    elif count > 1:
+        wavFiles = list(numpy.random.choice(wavFiles, count))
+    results = {}
+    for file in wavFiles:
+        results[file] = EvaluateOneWavFile(file, LPF=LPF, CUTOFF=CUTOFF, model=model,
+                                           CENTER_FREQUENCIES=CENTER_FREQUENCIES,
+                                           FILTERBANK_COEFFICIENTS=FILTERBANK_COEFFICIENTS)
+    print("Evaluating network on all files.")
+    print('              Total time:', time.time() - TotalTime)
+    print('')
+    return results
+
+
+def SNRdbToSNRlinear(SNRdb):
+    return 10 ** (SNRdb / 10.0)
+
+
+def RMS(signal):
+    """Root mean square of a signal (computed in float64: int16 squares would overflow)."""
+    return numpy.sqrt(numpy.mean(numpy.square(numpy.asarray(signal, dtype=numpy.float64))))
+
+
+def EvaluateWithNoise(file, LPF=False, CUTOFF=100, model='last_trained_model', CENTER_FREQUENCIES=None,
+                      FILTERBANK_COEFFICIENTS=None, SNRdB=-3, rng=None):
+    """`cnn evalnoise`: add Gaussian noise of standard deviation RMS(wave)/10^(SNRdB/10) (the reference's scaling,
+    Evaluating.py:199), save the noisy WAV under OutputWavFiles/addedNoise/, and evaluate the float64 waveform."""
+    from shutil import copyfile
+    from scipy.io import wavfile
+    print("File:\t\t{}".format(file))
+    print("Appyling gaussian noise, new SNR is {SNR}dB".format(SNR=SNRdB))
+    framerate, wavList = GetArrayFromWAV(file)
+    rng = rng or numpy.random
+    noise = rng.normal(scale=RMS(wavList) / SNRdbToSNRlinear(SNRdB), size=wavList.shape[0])
+    output = noise + wavList
+    os.makedirs(os.path.join('OutputWavFiles', 'addedNoise'), exist_ok=True)
+    baseName = os.path.join('OutputWavFiles', 'addedNoise',
+                            os.path.split(os.path.splitext(file)[0])[1]) + '{SNR}dB'.format(SNR=SNRdB)
+    newPath = baseName + '.WAV'
+    srcBasename = os.path.splitext(file)[0]
+    wavfile.write(newPath, framerate, output)
+    for ext in ('.FB', '.PHN', '.WRD'):
+        try:
+            copyfile(srcBasename + ext, baseName + ext)
+        except FileNotFoundError:
+            pass
+    print('New noisy WAVE file saved as', newPath)
+    scores, labels = EvaluateOneWavArray(output, framerate, newPath, model=model, LPF=LPF, CUTOFF=CUTOFF,
+                                         CENTER_FREQUENCIES=CENTER_FREQUENCIES,
+                                         FILTERBANK_COEFFICIENTS=FILTERBANK_COEFFICIENTS)
+    numpy.savez(baseName + '.F2CNN.npz', scores=scores, labels=labels)
+    print("\t\t{}\tdone !".format(file))
+    return scores, labels

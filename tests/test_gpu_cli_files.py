@@ -71,3 +71,32 @@ def test_prepare_and_eval_cli(tmp_path, monkeypatch, capsys):
     assert res["scores"].shape == (4000 - 1760, 2) and res["labels"].shape == (4000 - 1760,)
     out = capsys.readouterr().out
     assert "Total time:" in out and "done !" in out
+
+
+def test_evalnoise_and_evalrand(tmp_path, monkeypatch):
+    from f2cnn_amd.scripts.CNN import Evaluating
+    monkeypatch.chdir(tmp_path)
+    config.write_default()
+    os.makedirs(os.path.join("resources", "f2cnn", "TEST"))
+    paths = []
+    for i, n in enumerate((3000, 2600)):
+        p = os.path.join("resources", "f2cnn", "TEST", f"DR1.S{i}.SA1.WAV")
+        wavio.write_sphere(p, 16000, orc.synth_utterance(300 + i, n))
+        paths.append(p)
+    m = F2CNNModel.glorot(7)
+    m.save("last_trained_model.npz")
+    # evalnoise: the float64 noisy waveform goes through the float64-input filterbank kernel
+    rng = np.random.RandomState(1)
+    scores, labels = Evaluating.EvaluateWithNoise(paths[0], model=m, SNRdB=-3, rng=rng)
+    noisy_rate, noisy = wavio.read_audio(os.path.join("OutputWavFiles", "addedNoise", "DR1.S0.SA1-3dB.WAV"))
+    assert noisy_rate == 16000 and noisy.dtype == np.float64 and noisy.shape == (3000,)
+    coefs = orc.make_erb_filters(16000, orc.centre_freqs(16000, 128, 100))
+    env = orc.filter_and_envelope(noisy, coefs, False)
+    ref = orc.cnn_forward(orc.eval_input_tensor(env), dict(m.tensors))
+    np.testing.assert_allclose(scores, ref, atol=5e-4)
+    decided = np.abs(ref[:, 1] - ref[:, 0]) > 2e-3
+    np.testing.assert_array_equal(labels[decided], orc.labels_from_scores(ref)[decided])
+    # evalrand through the CLI: both files, model loaded once
+    assert cli.main(["cnn", "evalrand", "--model", "last_trained_model.npz"]) == 0
+    for p in paths:
+        assert os.path.exists(os.path.splitext(p)[0] + ".F2CNN.npz")

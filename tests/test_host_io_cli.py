@@ -80,9 +80,21 @@ def test_cli_parser():
     assert a.labelFile == "x.csv" and a.inputFile == "y.npy" and a.CUTOFF is None
     a = p.parse_args(["cnn", "eval", "-f", "a.WAV", "--lpf", "50", "-m", "w.npz"])
     assert a.cnn_command == "eval" and a.file == "a.WAV" and a.CUTOFF == 50 and a.model == "w.npz"
+    a = p.parse_args(["cnn", "evalnoise", "-f", "a.WAV", "-n", "-3"])
+    assert a.cnn_command == "evalnoise" and a.SNRdB == -3.0
+    a = p.parse_args(["cnn", "evalrand", "-c", "5"])
+    assert a.cnn_command == "evalrand" and a.count == 5 and a.file is None
     with pytest.raises(SystemExit):
         p.parse_args(["prepare", "organize"])
     assert cli.main([]) == 1
+    assert cli.main(["cnn", "eval"]) == 1
+
+
+def test_noise_helpers():
+    from f2cnn_amd.scripts.CNN import Evaluating
+    assert Evaluating.SNRdbToSNRlinear(10) == 10 and abs(Evaluating.SNRdbToSNRlinear(-3) - 0.5011872) < 1e-6
+    x = np.full(1000, 30000, np.int16)          # squares overflow int16/int32 arithmetic if not widened
+    assert abs(Evaluating.RMS(x) - 30000.0) < 1e-9
 
 
 def test_empty_corpus_exits_like_the_reference(tmp_path, monkeypatch, capsys):
