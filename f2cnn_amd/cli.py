@@ -4,6 +4,7 @@ package implements:
     python -m f2cnn_amd prepare filter
     python -m f2cnn_amd prepare envelope [--cutoff/-c HZ]
     python -m f2cnn_amd prepare input [--cutoff HZ] [--label/-l CSV] [--input/-i NPY]
+    python -m f2cnn_amd prepare features [--cutoff HZ]     (filter + envelope in one pass, not in the reference)
     python -m f2cnn_amd cnn eval --file/-f WAV [--lpf HZ] [--model/-m NPZ]
     python -m f2cnn_amd cnn evalnoise --file/-f WAV --noise/-n SNRdB [--lpf HZ] [--model/-m NPZ]
     python -m f2cnn_amd cnn evalrand [--count/-c N] [--lpf HZ] [--model/-m NPZ]
@@ -13,7 +14,7 @@ organize / label / train / plot need the licensed TIMIT+VTR corpora or Keras and
 """
 import argparse
 
-PREPARE = ("filter", "envelope", "input")
+PREPARE = ("filter", "envelope", "input", "features")
 CNN = ("eval", "evalnoise", "evalrand")
 
 
@@ -42,7 +43,7 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if 'prepare_command' in args:
         kwargs = {}
-        if args.prepare_command in ('envelope', 'input'):      # f2cnn.py:112-114
+        if args.prepare_command in ('envelope', 'input', 'features'):      # f2cnn.py:112-114
             kwargs['LPF'] = args.CUTOFF is not None
             kwargs['CUTOFF'] = args.CUTOFF
         if args.prepare_command == 'input':
@@ -54,6 +55,8 @@ def main(argv=None):
             from .scripts.processing.GammatoneFiltering import FilterAllOrganisedFiles as fn
         elif args.prepare_command == 'envelope':
             from .scripts.processing.EnvelopeExtraction import ExtractAllEnvelopes as fn
+        elif args.prepare_command == 'features':
+            from .scripts.processing.EnvelopeExtraction import FilterAndExtractAll as fn
         else:
             from .scripts.processing.InputGenerator import GenerateInputData as fn
         fn(**kwargs)

@@ -1,0 +1,34 @@
+"""File I/O pipeline around the GPU kernels.
+
+The reference hides disk latency behind one process per core (GammatoneFiltering.py:122-125,
+EnvelopeExtraction.py:145-149); here one process drives one GPU, so the reads of the next batch and the `.npy`
+writes of the previous one run on threads (NumPy file I/O releases the GIL) while the GPU works on the current
+batch. Results are written by the caller's `save` exactly as the reference names and formats them.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+
+def run_batches(items, load, compute, save, batch=32, readers=4, writers=4, max_pending_writes=64):
+    """items -> load(item) [threads] -> compute(list of (item, loaded)) -> iterable of (item, result)
+    -> save(item, result) [threads]. Order of `compute` calls follows `items`; returns the number of items saved."""
+    items = list(items)
+    if not items:
+        return 0
+    done = 0
+    with ThreadPoolExecutor(readers) as rpool, ThreadPoolExecutor(writers) as wpool:
+        def submit_loads(chunk):
+            return [(it, rpool.submit(load, it)) for it in chunk]
+        chunks = [items[s:s + batch] for s in range(0, len(items), batch)]
+        pending = submit_loads(chunks[0])
+        writes = []
+        for ci in range(len(chunks)):
+            loaded = [(it, f.result()) for it, f in pending]
+            pending = submit_loads(chunks[ci + 1]) if ci + 1 < len(chunks) else []
+            for it, res in compute(loaded):
+                writes.append(wpool.submit(save, it, res))
+                done += 1
+            while len(writes) > max_pending_writes:     # bound the host memory held by queued results
+                writes.pop(0).result()
+        for w in writes:
+            w.result()
+    return done

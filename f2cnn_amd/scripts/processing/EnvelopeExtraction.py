@@ -12,6 +12,7 @@ import time
 import numpy
 
 from ... import _lib
+from ...iopipe import run_batches
 from ...runtime import shard_for_rank
 
 FFT_PRECISION = _lib.FFT_F64 if os.environ.get("F2CNN_FFT", "f32").lower() in ("f64", "double") else _lib.FFT_F32
@@ -84,24 +85,85 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16):
         print("Not using Low Pass Filtering")
     print(len(gfbFiles), ".GFB.npy files found")
     mine = shard_for_rank(gfbFiles)
-    done = 0
-    for s in range(0, len(mine), batch_files):
-        names = mine[s:s + batch_files]
-        mats = []
-        for name in names:
-            print("File:\t{}".format(name))
-            mats.append(numpy.load(name))
+    progress = {"done": 0}
+
+    def load(name):
+        print("File:\t{}".format(name))
+        return numpy.load(name)
+
+    def compute(loaded):
         # one launch per distinct channel count (normally one)
         by_c = {}
-        for i, m in enumerate(mats):
+        for i, (_, m) in enumerate(loaded):
             by_c.setdefault(m.shape[0], []).append(i)
-        envs = [None] * len(mats)
+        envs = [None] * len(loaded)
         for idx in by_c.values():
-            for i, e in zip(idx, ExtractEnvelopesFromMatrices([mats[i] for i in idx], LPF, CUTOFF)):
+            for i, e in zip(idx, ExtractEnvelopesFromMatrices([loaded[i][1] for i in idx], LPF, CUTOFF)):
                 envs[i] = e
-        for name, e in zip(names, envs):
-            done += 1
-            SaveEnvelope(e, name, len(mine), done)
+        return [(loaded[i][0], envs[i]) for i in range(len(loaded))]
+
+    def save(name, e):
+        numpy.save(envelope_filename(name), e)
+        progress["done"] += 1
+        print("\t{:<50} done ! {}/{} Files.".format(envelope_filename(name), progress["done"], len(mine)))
+
+    run_batches(mine, load, compute, save, batch=batch_files)
     print("Extracted Envelopes from all files.")
+    print('              Total time:', time.time() - TotalTime)
+    print('')
+
+
+def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True):
+    """`prepare filter` followed by `prepare envelope` in ONE pass over the corpus: every
+    resources/f2cnn/*/*.WAV -> <base>.GFB.npy (unless keep_gfb is False) and <base>.ENV1.npy, through
+    f2_filterbank_envelope_fused. Nothing is read back from disk between the two stages (the reference writes the
+    16 MB .GFB.npy per second of audio and loads it again, f2cnn.py:17-18)."""
+    from ... import _lib
+    from ...gammatone import filters
+    from .GammatoneFiltering import GetArrayFromWAV, filterbank_from_config
+    TotalTime = time.time()
+    wavFiles = sorted(glob.glob(os.path.join("resources", "f2cnn", "*", "*.WAV")))
+    if not wavFiles:
+        print("NO WAV FILES FOUND, PLEASE ORGANIZE FILES")
+        exit(-1)
+    print("\n###############################\nFiltering and extracting envelopes of files in '{}'.".format(
+        os.path.split(wavFiles[0])[0]))
+    print(len(wavFiles), "files found")
+    _, coefs = filterbank_from_config()
+    coefs = numpy.ascontiguousarray(coefs, dtype=numpy.float64)
+    Cn = coefs.shape[0]
+    ctx = _lib.default_context()
+    mine = shard_for_rank(wavFiles)
+    progress = {"done": 0}
+
+    def load(name):
+        return GetArrayFromWAV(name)[1]
+
+    def compute(loaded):
+        args = [filters._wave_args(w) for _, w in loaded]
+        dt = args[0][1] if all(a[1] == args[0][1] for a in args) else _lib.WAVE_F64
+        dtype = numpy.int16 if dt == _lib.WAVE_I16 else numpy.float64
+        offsets = numpy.zeros(len(args) + 1, dtype=numpy.int64)
+        offsets[1:] = numpy.cumsum([a[0].shape[0] for a in args])
+        flat = numpy.concatenate([a[0].astype(dtype, copy=False) for a in args])
+        env = numpy.empty(Cn * int(offsets[-1]), dtype=numpy.float64)
+        gfb = numpy.empty_like(env) if keep_gfb else None
+        ctx.filterbank_envelope_fused(flat, dt, offsets, coefs, len(args), Cn, bool(LPF), CUTOFF if LPF else 0.0,
+                                      FFT_PRECISION, env, gfb, _lib.MEM_HOST)
+        for b, (name, _) in enumerate(loaded):
+            sl = slice(Cn * offsets[b], Cn * offsets[b + 1])
+            yield name, (env[sl].reshape(Cn, -1), gfb[sl].reshape(Cn, -1) if keep_gfb else None)
+
+    def save(name, res):
+        env, gfb = res
+        base = os.path.splitext(name)[0]
+        if gfb is not None:
+            numpy.save(base + '.GFB', gfb)
+        numpy.save(base + '.ENV' + str(METHOD), env)
+        progress["done"] += 1
+        print("\t{:<50} done ! {}/{} Files.".format(base + '.ENV' + str(METHOD), progress["done"], len(mine)))
+
+    run_batches(mine, load, compute, save, batch=batch_files)
+    print("Filtered and extracted envelopes of all files.")
     print('              Total time:', time.time() - TotalTime)
     print('')

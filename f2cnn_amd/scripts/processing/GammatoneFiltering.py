@@ -12,6 +12,7 @@ import numpy
 
 from ...config import F2Config
 from ...gammatone import filters
+from ...iopipe import run_batches
 from ...runtime import shard_for_rank
 from ...wavio import read_audio
 
@@ -66,19 +67,24 @@ def FilterAllOrganisedFiles(batch_files=32):
     print(len(wavFiles), "files found")
     _, coefs = filterbank_from_config()
     mine = shard_for_rank(wavFiles)
-    done = 0
-    for s in range(0, len(mine), batch_files):
-        names = mine[s:s + batch_files]
-        waves = []
-        for name in names:
-            print("Filtering:\t{}".format(name))
-            waves.append(GetArrayFromWAV(name)[1])
-        for name, m in zip(names, filters.erb_filterbank_batch(waves, coefs)):
-            gfb = os.path.splitext(name)[0] + '.GFB'
-            print("Saving:\t\t{}.npy".format(gfb))
-            saveGFBMatrix(gfb, m)
-            done += 1
-            print("\t\t{:<50} done ! {}/{} Files.".format(name, done, len(mine)))
+    progress = {"done": 0}
+
+    def load(name):
+        print("Filtering:\t{}".format(name))
+        return GetArrayFromWAV(name)[1]
+
+    def compute(loaded):
+        names = [n for n, _ in loaded]
+        return zip(names, filters.erb_filterbank_batch([w for _, w in loaded], coefs))
+
+    def save(name, m):
+        gfb = os.path.splitext(name)[0] + '.GFB'
+        print("Saving:\t\t{}.npy".format(gfb))
+        saveGFBMatrix(gfb, m)
+        progress["done"] += 1
+        print("\t\t{:<50} done ! {}/{} Files.".format(name, progress["done"], len(mine)))
+
+    run_batches(mine, load, compute, save, batch=batch_files)
     print("Filtered and Saved all files.")
     print('                Total time:', time.time() - TotalTime)
     print('')

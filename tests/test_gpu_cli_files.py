@@ -100,3 +100,24 @@ def test_evalnoise_and_evalrand(tmp_path, monkeypatch):
     assert cli.main(["cnn", "evalrand", "--model", "last_trained_model.npz"]) == 0
     for p in paths:
         assert os.path.exists(os.path.splitext(p)[0] + ".F2CNN.npz")
+
+
+def test_prepare_features_one_pass_equals_two_commands(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    config.write_default()
+    os.makedirs(os.path.join("resources", "f2cnn", "TRAIN"))
+    names = []
+    for i, n in enumerate((2000, 40000, 1234, 16000, 999)):      # incl. a long row and odd lengths
+        p = os.path.join("resources", "f2cnn", "TRAIN", f"DR3.M{i}.SX{i}.WAV")
+        wavio.write_sphere(p, 16000, orc.synth_utterance(500 + i, n))
+        names.append(os.path.splitext(p)[0])
+    assert cli.main(["prepare", "features", "--cutoff", "50"]) == 0
+    one = {b: (np.load(b + ".GFB.npy"), np.load(b + ".ENV1.npy")) for b in names}
+    for b in names:
+        os.remove(b + ".GFB.npy")
+        os.remove(b + ".ENV1.npy")
+    assert cli.main(["prepare", "filter"]) == 0 and cli.main(["prepare", "envelope", "-c", "50"]) == 0
+    for b in names:
+        gfb, env = np.load(b + ".GFB.npy"), np.load(b + ".ENV1.npy")
+        np.testing.assert_array_equal(gfb, one[b][0])
+        assert chan_relerr(one[b][1], env) <= 1e-12        # same float64 hand-off in both routes

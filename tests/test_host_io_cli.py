@@ -115,3 +115,27 @@ def test_shard_partition():
         parts = [runtime.shard(files, r, world) for r in range(world)]
         assert sorted(sum(parts, [])) == files
         assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_iopipe_order_and_completeness():
+    import threading
+    import time
+    from f2cnn_amd.iopipe import run_batches
+    seen, saved, lock = [], {}, threading.Lock()
+
+    def load(i):
+        time.sleep(0.001 * (i % 3))
+        return i * 10
+
+    def compute(loaded):
+        seen.append([i for i, _ in loaded])
+        return [(i, v + 1) for i, v in loaded]
+
+    def save(i, v):
+        with lock:
+            saved[i] = v
+
+    assert run_batches(range(23), load, compute, save, batch=5, readers=3, writers=2, max_pending_writes=4) == 23
+    assert seen == [list(range(s, min(s + 5, 23))) for s in range(0, 23, 5)]
+    assert saved == {i: i * 10 + 1 for i in range(23)}
+    assert run_batches([], load, compute, save) == 0
