@@ -197,6 +197,14 @@ def main():
         avg_s = total_ms / launches / 1e3
         achieved = algo[kname] / avg_s / 1e9
         pipeline_bytes = B * (2 * N + 8 * C * N)     # what the whole step must move at least (cfg2/cfg3)
+        # HBM bytes per launch from the PMC counters (collected separately with rocprofv3 --pmc and committed
+        # under profiles/; only valid for the batch it was measured on)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_c_traffic_cfg3.json")
+        if args.workload == "cfg3" and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("batch") == B and kname in tj and C == 128 and N == FS and args.fft == "f32":
+                traffic = tj[kname]["hbm_bytes_per_launch"]
         out = {
             "metric": "audio-seconds/sec through filterbank+envelope" + ("+CNN" if args.workload == "cfg4" else "")
                       + " (HIP, 1 MI355X per rank)",
@@ -211,7 +219,7 @@ def main():
             "config": {"workload": label, "batch_per_gpu": B, "channels": C, "samples_per_utterance": N,
                        "sample_rate": FS, "lpf_hz": lpf, "parallelism": f"utterance-sharded x{world}, no collective"},
             "roofline": {"bound": bound, "kernel": kname, "achieved": round(achieved, 1), "peak": peak,
-                         "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
+                         "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                          ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_flop_per_launch"):
                              algo[kname], "avg_launch_ms": round(avg_s * 1e3, 4), "launches_timed": launches},
             "kernels": {k: {"launches": n, "avg_ms": round(ms / n, 4),
