@@ -86,20 +86,24 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ x, cons
 }
 
 // ---- conv2..4: implicit GEMM on v_mfma_f32_32x32x2_f32 ----
-template <int CIN, int COUT, bool SAME, bool POOL, int WAVES>
+// NSPLIT waves share one task (one patch): each takes COUT/32/NSPLIT of the output tiles, so a 64-channel layer
+// keeps twice the waves per CU for the same LDS.
+template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT>
 __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __restrict__ in, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              int Hin, int Win, int64_t nwin) {
     constexpr int PS = CIN + 4;           // LDS pitch per pixel: 16-byte aligned and conflict-free for ds_read_b128
     constexpr int PATCH = 4 * PW * PS;    // floats per wave
-    constexpr int NT = COUT / 32;
+    constexpr int NT = COUT / 32 / NSPLIT;   // output tiles of this wave
+    constexpr int TPB = WAVES / NSPLIT;      // tasks (patches) per workgroup
     constexpr int PAD = SAME ? 1 : 0;
     constexpr int C4 = CIN / 4;           // float4 per pixel
     constexpr int HALF = CIN / 2;         // MFMA k = 0 takes channel s, k = 1 takes channel HALF + s
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* patch = lds_all + wave * PATCH;
+    const int ns = wave % NSPLIT;
+    float* patch = lds_all + (wave / NSPLIT) * PATCH;
 
     const int Ho = SAME ? Hin : Hin - 2, Wo = SAME ? Win : Win - 2;
     const int Hout = POOL ? Ho / 2 : Ho, Wout = POOL ? Wo / 2 : Wo;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     const int wneed = POOL ? (Wo / 2) * 2 : Wo;
     const int xtiles = (wneed + 31) / 32;
     const int64_t tasks = nwin * row_pairs * xtiles;
-    int64_t task = (int64_t)blockIdx.x * WAVES + wave;
+    int64_t task = (int64_t)blockIdx.x * TPB + wave / NSPLIT;
     const bool live = task < tasks;
     if (!live) task = tasks - 1;
     const int xt = (int)(task % xtiles);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     // stage the 4 x 34 x CIN patch with 16-byte loads (zero outside the image: 'same' padding / tile overhang)
     const float* img = in + win * (int64_t)Hin * Win * CIN;
 #pragma unroll 4
-    for (int e = lane; e < 4 * PW * C4; e += 64) {
+    for (int e = lane + 64 * ns; e < 4 * PW * C4; e += 64 * NSPLIT) {
         const int r = e / (PW * C4);
         const int rem = e - r * (PW * C4);
         const int p = rem / C4, c4 = rem - p * C4;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     // wt[tap][h][s/4][cout][s%4].
     const int i = lane & 31, h = lane >> 5;
     const float* pa0 = patch + i * PS + h * HALF;
-    const float4* wq = reinterpret_cast<const float4*>(w) + (int64_t)h * (HALF / 4) * COUT + i;
+    const float4* wq = reinterpret_cast<const float4*>(w) + (int64_t)h * (HALF / 4) * COUT + ns * NT * 32 + i;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     float* o = out + win * (int64_t)Hout * Wout * COUT;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = nt * 32 + i;
+        const int co = (ns * NT + nt) * 32 + i;
         const float bv = bias[co];
         if constexpr (POOL) {
 #pragma unroll
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256) void k_dense2_softmax(const float* __restrict_
     if (labels) labels[i] = s1 > s0 ? 1 : 0;   // ties -> 0 ("falling"), Evaluating.py:87
 }
 
-template <int CIN, int COUT, bool SAME, bool POOL, int WAVES>
+template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT>
 int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, float* out, int Hin, int Win, int64_t n) {
     const int Ho = SAME ? Hin : Hin - 2, Wo = SAME ? Win : Win - 2;
     const int row_pairs = POOL ? Ho / 2 : (Ho + 1) / 2;
@@ -308,11 +312,12 @@ int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, fl
     const int xtiles = (wneed + 31) / 32;
     const int64_t tasks = n * row_pairs * xtiles;
     if (tasks <= 0) return F2_OK;
-    constexpr size_t lds = sizeof(float) * WAVES * 4 * PW * (CIN + 4);
-    auto kern = k_conv3x3_mfma<CIN, COUT, SAME, POOL, WAVES>;
+    constexpr int TPB = WAVES / NSPLIT;
+    constexpr size_t lds = sizeof(float) * TPB * 4 * PW * (CIN + 4);
+    auto kern = k_conv3x3_mfma<CIN, COUT, SAME, POOL, WAVES, NSPLIT>;
     if (lds > 64 * 1024)
         F2_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t blocks = (tasks + WAVES - 1) / WAVES;
+    const int64_t blocks = (tasks + TPB - 1) / TPB;
     F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, ctx->stream, in, w, b, out, Hin, Win, n);
     F2_HIP(ctx, hipGetLastError());
@@ -340,9 +345,9 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
     hipLaunchKernelGGL(k_conv1, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, d_x, cnn->t(0), cnn->t(1),
                        a1, d.H1, d.W1, npix);
     F2_HIP(ctx, hipGetLastError());
-    F2_TRY((launch_conv<C1, C2, false, true, 4>(ctx, a1, cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n)));
-    F2_TRY((launch_conv<C2, C3, true, false, 4>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
-    F2_TRY((launch_conv<C3, C4, false, true, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
+    F2_TRY((launch_conv<C1, C2, false, true, 4, 1>(ctx, a1, cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n)));
+    F2_TRY((launch_conv<C2, C3, true, false, 8, 2>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
+    F2_TRY((launch_conv<C3, C4, false, true, 4, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
     {
         hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((n + 31) / 32)), dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8),
                            cnn->t(9), a5, d.flat, n);

@@ -467,15 +467,18 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     }
     // The chunk is cut into NS sub-chunks whose recurrences run interleaved (independent float64 chains:
     // the FMA latency is ~25 cycles, a single 32-sample chain would cost more than the arithmetic).
-    constexpr int NS = L >= 16 ? 4 : 1;
+    constexpr int NS = L >= 64 ? 8 : L >= 16 ? 4 : 1;   // sub-chunks of at most 16 samples
     constexpr int LS = L / NS;
     F yzs[L];                 // zero-state response of every sub-chunk
     double zend[NS];
     {
-        F ep[NS];
+        // inside a sub-chunk (<= 16 samples) the recurrence runs in F: the rounding of so few steps stays at a few
+        // ulp of the (positive) partial sums; everything that crosses sub-chunks, chunks and waves is float64
+        F ep[NS], z[NS];
+        const F na1f = (F)na1;
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-            zend[q] = 0.0;
+            z[q] = F(0);
             ep[q] = q == 0 ? eprev : rl[(q * LS - 1) * TP + tid];
         }
 #pragma unroll
@@ -483,11 +486,13 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 const F e = rl[(q * LS + j) * TP + tid];   // samples past n hold |0| = 0
-                zend[q] = fma(na1, zend[q], (double)(b0f * (e + ep[q])));
-                yzs[q * LS + j] = (F)zend[q];
+                z[q] = na1f * z[q] + b0f * (e + ep[q]);
+                yzs[q * LS + j] = z[q];
                 ep[q] = e;
             }
         }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) zend[q] = (double)z[q];
     }
     // gs = (-a1)^LS, g = (-a1)^L
     double gs = na1;
