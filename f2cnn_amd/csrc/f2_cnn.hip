@@ -202,7 +202,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
 }
 
 // ---- dense1: (n, K) x (K, 516) on the same MFMA ----
-// One 6-wave workgroup = 32 windows x all 17 output tiles (wave w owns tiles w, w+6, w+12). K is walked in
+// One 6-wave workgroup = 32 windows x 6 of the 17 output tiles (blockIdx.y picks the group, one tile per wave, so a
+// 4096-window chunk is 384 workgroups: enough to fill 256 CUs). K is walked in
 // chunks of 64: the 32 x 64 activation chunk is staged in LDS (double buffered, 16-byte loads, pitch 68) and
 // read back as the A operand with ds_read_b128; the B operand comes from the re-laid-out weights
 // wt[chunk][h][q][n (padded to 544)][4], one 16-byte load per four MFMA steps.
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __re
                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                int K, int64_t n) {
     constexpr int PS = D1_KC + 4;
-    constexpr int TPW = (D1_TILES + D1_WAVES - 1) / D1_WAVES;   // tiles per wave (3)
+    constexpr int TPW = 1;                                       // tiles per wave
     __shared__ __attribute__((aligned(16))) float As[2][32 * PS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t w0 = (int64_t)blockIdx.x * 32;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __re
             float4 bv[TPW];
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                const int nt = wave + t * D1_WAVES;
+                const int nt = blockIdx.y * D1_WAVES + wave + t * D1_WAVES;
                 bv[t] = nt < D1_TILES ? pb[(int64_t)q * D1_NPAD + nt * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -258,14 +259,14 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __re
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
                     const float b = r == 0 ? bv[t].x : r == 1 ? bv[t].y : r == 2 ? bv[t].z : bv[t].w;
-                    if (wave + t * D1_WAVES < D1_TILES) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[r], b, acc[t], 0, 0, 0);
+                    if (blockIdx.y * D1_WAVES + wave + t * D1_WAVES < D1_TILES) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[r], b, acc[t], 0, 0, 0);
                 }
         }
         __syncthreads();
     }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int nt = wave + t * D1_WAVES;
+        const int nt = blockIdx.y * D1_WAVES + wave + t * D1_WAVES;
         const int col = nt * 32 + i;
         if (nt < D1_TILES && col < D1) {
             const float b = bias[col];
@@ -349,7 +350,7 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
     F2_TRY((launch_conv<C2, C3, true, false, 8, 2>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
     F2_TRY((launch_conv<C3, C4, false, true, 4, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
     {
-        hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((n + 31) / 32)), dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8),
+        hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((n + 31) / 32), (D1_TILES + D1_WAVES - 1) / D1_WAVES), dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8),
                            cnn->t(9), a5, d.flat, n);
         F2_HIP(ctx, hipGetLastError());
     }
