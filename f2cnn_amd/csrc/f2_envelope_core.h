@@ -89,4 +89,17 @@ __device__ __forceinline__ double shfl_up_f64(double v, int d) {
     return __hiloint2double(hi, lo);
 }
 
+// DPP lane move (gfx9 encodings: 0x110+n row_shr:n, 0x142 row_bcast:15, 0x143 row_bcast:31); lanes without a source
+// lane, or in rows masked out by ROW_MASK, receive 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 }  // namespace f2fft
