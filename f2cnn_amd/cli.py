@@ -3,6 +3,7 @@ package implements:
 
     python -m f2cnn_amd prepare filter
     python -m f2cnn_amd prepare envelope [--cutoff/-c HZ]
+    python -m f2cnn_amd prepare label                       (needs the VTR .FB and TIMIT .PHN side files)
     python -m f2cnn_amd prepare input [--cutoff HZ] [--label/-l CSV] [--input/-i NPY]
     python -m f2cnn_amd prepare features [--cutoff HZ]     (filter + envelope in one pass, not in the reference)
     python -m f2cnn_amd cnn eval --file/-f WAV [--lpf HZ] [--model/-m NPZ]
@@ -10,11 +11,11 @@ package implements:
     python -m f2cnn_amd cnn evalrand [--count/-c N] [--lpf HZ] [--model/-m NPZ]
     python -m f2cnn_amd --configure            (writes configF2CNN.conf with the reference's defaults)
 
-organize / label / train / plot need the licensed TIMIT+VTR corpora or Keras and stay with the reference.
+organize / train / plot need the licensed TIMIT+VTR corpora or Keras and stay with the reference.
 """
 import argparse
 
-PREPARE = ("filter", "envelope", "input", "features")
+PREPARE = ("filter", "envelope", "label", "input", "features")
 CNN = ("eval", "evalnoise", "evalrand")
 
 
@@ -55,6 +56,8 @@ def main(argv=None):
             from .scripts.processing.GammatoneFiltering import FilterAllOrganisedFiles as fn
         elif args.prepare_command == 'envelope':
             from .scripts.processing.EnvelopeExtraction import ExtractAllEnvelopes as fn
+        elif args.prepare_command == 'label':
+            from .scripts.processing.LabelDataGenerator import GenerateLabelData as fn
         elif args.prepare_command == 'features':
             from .scripts.processing.EnvelopeExtraction import FilterAndExtractAll as fn
         else:
