@@ -435,134 +435,18 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     }
     F2_STAMP(5);
     if constexpr (FULL0) {
-        // Low-pass in the register layout of the FFT (no transposition through LDS): thread t holds the sample
-        // pairs (2m, 2m+1), m = t + NT*jj, i.e. one pair in each of NBLK blocks of 2*NT consecutive samples.
-        //   y[n] = q y[n-1] + u[n],  u[n] = b0 (e[n] + e[n-1]),  q = -a1
-        // pair:  z0 = u0, z1 = u1 + q u0                      (zero state at the pair start)
-        // block: inclusive scan of z1 over the NT pairs with multiplier q^2 (wave shuffles in F, then the wave
-        //        totals and everything above them in float64)
-        // row:   the NBLK block totals are chained sequentially (q^(2 NT) per block)
-        // and the outputs leave as coalesced 16-byte stores straight from the registers.
+        // block jj = i + ITER0*j of this thread's envelope pairs sits in v[i*R0 + brev(j)]
         constexpr int NBLK = ITER0 * R0;
-        constexpr int NW = NT / 64;
-        F* e1s = rl;                                                   // [NBLK][NT] odd samples, for e[n-1]
-        double* wtot = reinterpret_cast<double*>(smem + sizeof(F) * NBLK * NT);   // [NBLK][NW] wave totals
-        double* cwl = wtot + NBLK * NW;                                // [NBLK][NW] carry into each wave
-        double* btot = cwl + NBLK * NW;                                // [NBLK] block totals
-        static_assert(NBLK <= NT, "one thread per block chains the wave totals");
-        static_assert(sizeof(F) * NBLK * NT + sizeof(double) * (2 * NBLK * NW + NBLK) <= (size_t)LDS_BYTES, "LDS too small");
-        const int lane = tid & 63, wv = tid >> 6;
-        const double q = -P.a1;
-        const F qf = (F)q, b0f = (F)P.b0;
-        // e(jj): envelope pair of block jj = i + ITER0*j sits in v[i*R0 + brev(j)]
-#pragma unroll
-        for (int i = 0; i < ITER0; ++i)
-#pragma unroll
-            for (int j = 0; j < R0; ++j) e1s[(i + ITER0 * j) * NT + tid] = v[i * R0 + brev<R0>(j)].im;
-        // powers of q^2 for the wave scan, q^(2(lane+1)), q^128, q^(2 tid), q^(2 NT)
-        double g[6];
-        g[0] = q * q;
-#pragma unroll
-        for (int d = 1; d < 6; ++d) g[d] = g[d - 1] * g[d - 1];
-        const double gw = g[5] * g[5];                                 // q^128: one wave of pairs
-        double gl = 1.0;                                               // q^(2 (lane+1))
-        {
-            double gp = g[0];
-            for (int bits = lane + 1; bits; bits >>= 1) {
-                if (bits & 1) gl *= gp;
-                gp *= gp;
-            }
-        }
-        double gt = 1.0, gblk = 1.0;                                   // q^(2 tid), q^(2 NT)
-        {
-            double gp = g[0];
-            for (int bits = tid; bits; bits >>= 1) {
-                if (bits & 1) gt *= gp;
-                gp *= gp;
-            }
-            gp = g[0];
-            for (int bits = NT; bits; bits >>= 1) {
-                if (bits & 1) gblk *= gp;
-                gp *= gp;
-            }
-        }
-        __syncthreads();
-        F u0[NBLK], u1[NBLK], sc[NBLK];
+        static_assert(lowpass_lds_bytes<F, NT, NBLK>() <= (size_t)LDS_BYTES, "LDS too small");
+        F er[NBLK], ei[NBLK];
 #pragma unroll
         for (int i = 0; i < ITER0; ++i)
 #pragma unroll
             for (int j = 0; j < R0; ++j) {
-                const int jj = i + ITER0 * j;
-                const cpx<F> e = v[i * R0 + brev<R0>(j)];
-                const F eprev = tid > 0 ? e1s[jj * NT + tid - 1] : (jj > 0 ? e1s[(jj - 1) * NT + NT - 1] : F(0));
-                u0[jj] = b0f * (e.re + eprev);
-                u1[jj] = b0f * (e.im + e.re);
-                sc[jj] = u1[jj] + qf * u0[jj];
+                er[i + ITER0 * j] = v[i * R0 + brev<R0>(j)].re;
+                ei[i + ITER0 * j] = v[i * R0 + brev<R0>(j)].im;
             }
-        // inclusive weighted scan over the 64 pairs of the wave (all NBLK blocks interleaved) on DPP lane moves:
-        // row_shr 1,2,4,8 inside each row of 16 lanes (lanes without a source read 0), then row_bcast:15 brings the
-        // previous row's total into rows 1 and 3, and row_bcast:31 lane 31's total into rows 2 and 3
-        {
-            const F g1 = (F)g[0], g2 = (F)g[1], g4 = (F)g[2], g8 = (F)g[3];
-            F m16 = F(1), m32 = F(1);                                  // (q^2)^((lane&15)+1), (q^2)^((lane&31)+1)
-            {
-                double a = 1.0, b = 1.0, gp = g[0];
-                for (int bit = 0; bit < 5; ++bit) {
-                    if ((((lane & 15) + 1) >> bit) & 1) a *= gp;
-                    if ((((lane & 31) + 1) >> bit) & 1) b *= gp;
-                    gp *= gp;
-                }
-                b = (((lane & 31) + 1) >> 5) & 1 ? b * gp : b;
-                m16 = (F)a;
-                m32 = (F)b;
-            }
-#pragma unroll
-            for (int jj = 0; jj < NBLK; ++jj) {
-                sc[jj] += g1 * dpp_mov<0x111, 0xF>(sc[jj]);
-                sc[jj] += g2 * dpp_mov<0x112, 0xF>(sc[jj]);
-                sc[jj] += g4 * dpp_mov<0x114, 0xF>(sc[jj]);
-                sc[jj] += g8 * dpp_mov<0x118, 0xF>(sc[jj]);
-                sc[jj] += m16 * dpp_mov<0x142, 0xA>(sc[jj]);
-                sc[jj] += m32 * dpp_mov<0x143, 0xC>(sc[jj]);
-            }
-        }
-        if (lane == 63) {
-#pragma unroll
-            for (int jj = 0; jj < NBLK; ++jj) wtot[jj * NW + wv] = (double)sc[jj];
-        }
-        __syncthreads();
-        // one thread per block chains the NW wave totals: cwl[jj][w] = zero-state value of block jj at the end of
-        // wave w-1, btot[jj] = at the end of the block
-        if (tid < NBLK) {
-            double c = 0.0;
-#pragma unroll
-            for (int w2 = 0; w2 < NW; ++w2) {
-                const double t = wtot[tid * NW + w2];
-                cwl[tid * NW + w2] = c;
-                c = fma(gw, c, t);
-            }
-            btot[tid] = c;
-        }
-        __syncthreads();
-        const bool pairs_ok = al16 && (n & 1) == 0;
-        double ycarry = 0.0;                                           // true y at the end of the previous block
-#pragma unroll
-        for (int jj = 0; jj < NBLK; ++jj) {
-            const double cw = cwl[jj * NW + wv];
-            const double sin_ = fma(gl, cw, (double)sc[jj]);           // zero-state value at the end of this pair
-            const double up = dpp_mov<0x138, 0xF>(sin_);               // wave_shr:1
-            const double sprev = lane > 0 ? up : cw;                   // ... at the end of the previous pair
-            const double y0 = fma(q, fma(gt, ycarry, sprev), (double)u0[jj]);
-            const double y1 = fma(q, y0, (double)u1[jj]);
-            const int i0 = 2 * (tid + NT * jj);
-            if (pairs_ok) {
-                if (i0 < n) *reinterpret_cast<double2*>(y + i0) = make_double2(y0, y1);
-            } else {
-                if (i0 < n) y[i0] = y0;
-                if (i0 + 1 < n) y[i0 + 1] = y1;
-            }
-            ycarry = fma(gblk, ycarry, btot[jj]);
-        }
+        lowpass_pairs_store<F, NT, NBLK>(er, ei, P.a1, P.b0, smem, y, n, al16 && (n & 1) == 0, tid);
         return;
     }
     // With the low-pass the envelope goes to LDS, TRANSPOSED: thread t will own the contiguous samples
