@@ -30,12 +30,17 @@
 // Bound: HBM, 16 bytes per sample-channel (8 read + 8 written).
 #include <cmath>
 
+#include <cstdlib>
+
 #include "f2_envelope_core.h"
 
 using namespace f2fft;
 
 namespace {
 
+#ifndef F2_PLAN13_PASSES
+#define F2_PLAN13_PASSES 4
+#endif
 // threads per workgroup: 256, or 512 where 256 threads would need more than 256 registers each
 template <typename F, int LOG2H>
 constexpr int threads_for() { return LOG2H >= 13 ? 512 : 256; }
@@ -45,6 +50,10 @@ constexpr int min_waves_for() {
     return (sizeof(F) == 4 && LOG2H == 13) ? 4 : (sizeof(F) == 4 && LOG2H <= 12) ? 2 : (sizeof(F) == 8 && LOG2H <= 12) ? 2 : 2;
 }
 
+// Whether pass 0 derives its 15 twiddles per butterfly from two loaded ones (radix-16 first pass, float transforms)
+template <typename F, int LOG2H>
+constexpr bool derive_tw0() { return sizeof(F) == 4 && LOG2H >= 11 && LOG2H <= 13; }
+
 // Whether the Hilbert pair step is folded into the inverse transform's first pass (needs ~3x the pass's points in
 // registers for a moment: only where the register budget allows) or runs as its own sweep over LDS.
 template <typename F, int LOG2H>
@@ -53,9 +62,6 @@ constexpr bool fuse_hilbert() { return LOG2H >= 1 && LOG2H <= 12 && sizeof(F) ==
 // ---- radix plan: symmetric (first radix == last radix), radices 2..32 ----
 // H = 8192 (the 1 s / 16 kHz row) runs as 16-8-4-16 on 512 threads: 16 points per thread in every pass keeps
 // the kernel under 128 registers, i.e. 16 waves per CU to hide LDS / barrier / HBM latency.
-#ifndef F2_PLAN13_PASSES
-#define F2_PLAN13_PASSES 4
-#endif
 constexpr int plan_npass(int h) {
     return h == 0 ? 0 : h <= 5 ? 1 : h <= 10 ? ((h & 1) ? 3 : 2) : (h == 13 && F2_PLAN13_PASSES == 4) ? 4 : 3;
 }
@@ -92,7 +98,10 @@ constexpr int plan_tw_offset(int h, int pass) {
     for (int i = 0; i < pass; ++i) o += plan_tw_count(h, i);
     return o;
 }
-constexpr int plan_tw_total(int h) { return plan_tw_offset(h, plan_npass(h)); }   // then H/2+1 entries of V
+constexpr int plan_tw_total(int h) { return plan_tw_offset(h, plan_npass(h)); }
+// The tables of passes >= 1 are small (a pass with stride S has only NB/S distinct twiddle columns): each workgroup
+// copies them to LDS once, so only pass 0 (one distinct column per butterfly) reads its twiddles from global memory.
+constexpr int plan_tw_lds_count(int h) { return plan_npass(h) >= 2 ? plan_tw_total(h) - plan_tw_offset(h, 1) : 0; }   // then H/2+1 entries of V
 
 // LDS index padding of the complex array: one extra slot per 16
 __device__ __forceinline__ int cpad(int i) { return i + (i >> 4); }
@@ -105,8 +114,10 @@ constexpr int cpad_size(int h) { return h + (h >> 4) + 1; }
 // registers, the conjugated and 1/H-scaled packed spectrum of the Hilbert transform
 //   W[m] = i sin(t_m) Z[m] + cos(t_m) conj(Z[H-m]),  t_m = 2 pi m / M,  W[0] = 0
 // so the spectrum never makes a separate trip through LDS.
-template <typename F, int LOG2H, int PASS, bool SRC_REGS, bool DST_REGS, int PTV, int NT, bool HILBERT = false>
-__device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__ tw, int tid, cpx<F> (&v)[PTV]) {
+template <typename F, int LOG2H, int PASS, bool SRC_REGS, bool DST_REGS, int PTV, int NT, bool HILBERT = false,
+          bool T0REGS = false>
+__device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__ tw, const cpx<F>* twl, int tid,
+                                         cpx<F> (&v)[PTV]) {
     constexpr int H = 1 << LOG2H;
     constexpr int R = 1 << plan_bits(LOG2H, PASS);
     constexpr int LOG2S = plan_shift(LOG2H, PASS);
@@ -121,7 +132,11 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
             const int bf = tid + i * NT;
+#ifdef F2_KO_LDS
+            if (bf < 0) {
+#else
             if (FULL || bf < NB) {
+#endif
                 // cpad(bf + j*NB) = cpad(bf) + j*(NB + NB/16) when 16 | NB: one base + immediate offsets
                 if constexpr (NB % 16 == 0) {
                     const cpx<F>* src = lds + cpad(bf);
@@ -155,14 +170,49 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
     for (int i = 0; i < ITER; ++i) {
         const int bf = tid + i * NT;
         if (FULL || bf < NB) {
+#ifndef F2_KO_DFT   // knock-outs: timing experiments only (tools/build_variant.sh), results are wrong
             dft<R>(&v[i * R]);   // X[k] now sits in v[i*R + brev<R>(k)]
+#endif
+#ifdef F2_KO_TW   // bit mask of passes that skip their twiddles
+            if constexpr (!LAST && !((F2_KO_TW >> PASS) & 1)) {
+#else
             if constexpr (!LAST) {
-                const cpx<F>* twq = twp + (bf >> LOG2S);
+#endif
+                const cpx<F>* twq = (PASS >= 1 ? twl + (plan_tw_offset(LOG2H, PASS) - plan_tw_offset(LOG2H, 1)) : twp) +
+                                    (bf >> LOG2S);
+                if constexpr (PASS == 0 && T0REGS && R == 16) {
+                    // pass 0 has one distinct twiddle column per butterfly: load w and w^4 (two coalesced loads from
+                    // an 8 KB-per-workgroup slice that stays in L1) and form the other 13 powers by products,
+                    // at most three roundings deep, instead of 15 loads from a 60 KB table
+                    cpx<F> w[R];
+                    w[1] = twq[0];
+                    w[4] = twq[3 * (NB / S)];
+                    w[2] = cmul(w[1], w[1]);
+                    w[3] = cmul(w[2], w[1]);
+                    w[8] = cmul(w[4], w[4]);
+                    w[5] = cmul(w[4], w[1]);
+                    w[6] = cmul(w[4], w[2]);
+                    w[7] = cmul(w[4], w[3]);
+                    w[12] = cmul(w[8], w[4]);
+                    w[9] = cmul(w[8], w[1]);
+                    w[10] = cmul(w[8], w[2]);
+                    w[11] = cmul(w[8], w[3]);
+                    w[13] = cmul(w[12], w[1]);
+                    w[14] = cmul(w[12], w[2]);
+                    w[15] = cmul(w[12], w[3]);
 #pragma unroll
-                for (int k = 1; k < R; ++k)
-                    v[i * R + brev<R>(k)] = cmul(v[i * R + brev<R>(k)], twq[(k - 1) * (NB / S)]);
+                    for (int k = 1; k < R; ++k) v[i * R + brev<R>(k)] = cmul(v[i * R + brev<R>(k)], w[k]);
+                } else {
+#pragma unroll
+                    for (int k = 1; k < R; ++k)
+                        v[i * R + brev<R>(k)] = cmul(v[i * R + brev<R>(k)], twq[(k - 1) * (NB / S)]);
+                }
             }
+#ifdef F2_KO_LDS
+            if (bf < 0) {
+#else
             if constexpr (!DST_REGS) {
+#endif
                 const int q = bf & (S - 1);
                 const int base = q + (bf - q) * R;
                 if constexpr (S % 16 == 0) {
@@ -179,23 +229,24 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
     if constexpr (!DST_REGS) __syncthreads();
 }
 
-template <typename F, int LOG2H, bool INVERSE, int PTV, int NT, int PASS = 0>
-__device__ __forceinline__ void fft_all(cpx<F>* lds, const cpx<F>* __restrict__ tw, int tid, cpx<F> (&v)[PTV]) {
+template <typename F, int LOG2H, bool INVERSE, int PTV, int NT, bool T0REGS = false, int PASS = 0>
+__device__ __forceinline__ void fft_all(cpx<F>* lds, const cpx<F>* __restrict__ tw, const cpx<F>* twl, int tid,
+                                        cpx<F> (&v)[PTV]) {
     constexpr int NP = plan_npass(LOG2H);
     if constexpr (PASS < NP) {
         constexpr bool SRC = !INVERSE && PASS == 0;
         constexpr bool DST = INVERSE && PASS == NP - 1;
-        fft_pass<F, LOG2H, PASS, SRC, DST, PTV, NT, INVERSE && PASS == 0 && fuse_hilbert<F, LOG2H>()>(lds, tw, tid, v);
-        fft_all<F, LOG2H, INVERSE, PTV, NT, PASS + 1>(lds, tw, tid, v);
+        fft_pass<F, LOG2H, PASS, SRC, DST, PTV, NT, INVERSE && PASS == 0 && fuse_hilbert<F, LOG2H>(), T0REGS>(lds, tw, twl, tid, v);
+        fft_all<F, LOG2H, INVERSE, PTV, NT, T0REGS, PASS + 1>(lds, tw, twl, tid, v);
     }
 }
 
-// Diagnostic build only (-DF2_STAMPS): wave 0 of every workgroup records s_memtime at the phase boundaries.
+// Diagnostic build only (-DF2_STAMPS): wave 0 of every workgroup records s_memrealtime (100 MHz) at the phase boundaries.
 #ifdef F2_STAMPS
 #define F2_STAMP(k)                                          \
     do {                                                     \
         __builtin_amdgcn_sched_barrier(0);                   \
-        st[k] = __builtin_amdgcn_s_memtime();                \
+        st[k] = __builtin_amdgcn_s_memrealtime();              \
         __builtin_amdgcn_sched_barrier(0);                   \
     } while (0)
 #else
@@ -204,17 +255,6 @@ __device__ __forceinline__ void fft_all(cpx<F>* lds, const cpx<F>* __restrict__ 
     } while (0)
 #endif
 
-struct EnvParams {
-    const double* gfb;
-    double* env;
-    const int64_t* offsets;
-    const int* ulist;  // utterances served by this launch (NULL: identity)
-    int C;
-    int lpf;
-    int f32_in;        // input rows are float32 at the start of their float64 slot (hand-off from K1)
-    unsigned long long* stamps;   // diagnostic build only
-    double b0, a1;     // y[n] = b0 (e[n] + e[n-1]) - a1 y[n-1]
-};
 
 template <typename F, int LOG2H>
 __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>())) void k_envelope(EnvParams P, const cpx<F>* __restrict__ tw) {
@@ -235,6 +275,8 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     __shared__ double wave_tot[NT / 64];
     __shared__ F qpow[L];   // (-a1)^(j+1), j < L
+    constexpr int TWL = plan_tw_lds_count(LOG2H);
+    __shared__ __attribute__((aligned(16))) cpx<F> twl[TWL > 0 ? TWL : 1];   // twiddles of passes >= 1
     cpx<F>* lds = reinterpret_cast<cpx<F>*>(smem);
     F* rl = reinterpret_cast<F*>(smem);
     const cpx<F>* __restrict__ V = tw + plan_tw_total(LOG2H);   // exp(-2 pi i k / M), k <= H/2
@@ -254,6 +296,8 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     unsigned long long st[10] = {0};
 #endif
     F2_STAMP(0);
+    // (visible to every wave after the first pass's barrier; pass 0 never reads it)
+    for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2H, 1) + i];
     // 1. load: point (i, j) of this thread is m = tid + i*NT + j*NB0
     constexpr bool FULL0 = NB0 % NT == 0;
     cpx<F> v[PT];
@@ -338,7 +382,8 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     }
     F2_STAMP(1);
     // 2. forward transform (first pass straight from the registers)
-    fft_all<F, LOG2H, false, PT, NT>(lds, tw, tid, v);
+    constexpr bool T0R = derive_tw0<F, LOG2H>();
+    fft_all<F, LOG2H, false, PT, NT, T0R>(lds, tw, twl, tid, v);
     F2_STAMP(2);
     // 3. packed spectrum of the Hilbert transform, conjugated and scaled by 1/H for step 4:
     //    W[k] = i sin(t_k) Z[k] + cos(t_k) conj(Z[H-k]), W[0] = 0. Either folded into the first pass of
@@ -376,7 +421,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     }
     F2_STAMP(3);
     // 4. inverse transform (forward transform of the conjugate); outputs stay in v
-    fft_all<F, LOG2H, true, PT, NT>(lds, tw, tid, v);
+    fft_all<F, LOG2H, true, PT, NT, T0R>(lds, tw, twl, tid, v);
     if constexpr (LOG2H == 0) v[0] = {F(0), F(0)};   // H = 1: W[0] = 0, the envelope is |x|
 
     F2_STAMP(4);
@@ -447,6 +492,12 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
                 ei[i + ITER0 * j] = v[i * R0 + brev<R0>(j)].im;
             }
         lowpass_pairs_store<F, NT, NBLK>(er, ei, P.a1, P.b0, smem, y, n, al16 && (n & 1) == 0, tid);
+#ifdef F2_STAMPS
+        F2_STAMP(6);
+        st[7] = st[8] = st[9] = st[6];
+        if (tid == 0 && P.stamps)
+            for (int k = 0; k < 10; ++k) P.stamps[(size_t)blockIdx.x * 10 + k] = st[k];
+#endif
         return;
     }
     // With the low-pass the envelope goes to LDS, TRANSPOSED: thread t will own the contiguous samples
@@ -729,9 +780,19 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
             for (int k = 1; k < 10; ++k) acc[k] += (double)(h[r * 10 + k] - h[r * 10 + k - 1]);
         static const char* names[10] = {"", "load", "fwd fft", "hilbert pairs", "inv fft", "magnitude", "transposed write",
                                         "lpf chunk+scan", "lpf carry+apply", "copy out"};
-        fprintf(stderr, "[stamps] mean cycles per workgroup (s_memtime, 100 MHz ticks x clock):");
+        fprintf(stderr, "[stamps] mean cycles per workgroup (s_memrealtime, 10 ns ticks):");
         for (int k = 1; k < 10; ++k) fprintf(stderr, " %s=%.0f", names[k], acc[k] / rows);
         fprintf(stderr, "\n");
+        // residency: sum of workgroup lifetimes / kernel span = workgroups alive at once (chip-wide)
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double life = 0;
+        for (size_t r = 0; r < rows; ++r) {
+            t0 = std::min(t0, h[r * 10]);
+            t1 = std::max(t1, h[r * 10 + 9]);
+            life += (double)(h[r * 10 + 9] - h[r * 10]);
+        }
+        fprintf(stderr, "[stamps] mean workgroup lifetime %.1f ticks, kernel span %.0f ticks, workgroups alive at once %.1f\n",
+                life / rows, (double)(t1 - t0), life / (double)(t1 - t0));
     }
 #endif
     return F2_OK;

@@ -1,6 +1,10 @@
 """Ablation probe for K2 on device buffers: times f2_envelope_batch / fused in a few modes."""
 import sys, time, numpy as np
+import os
 sys.path.insert(0, "/root/repo")
+if os.environ.get("F2CNN_PROBE_LIB"):   # a tools/build_variant.sh library
+    from f2cnn_amd import build
+    build.LIB_PATH = os.path.abspath(os.environ["F2CNN_PROBE_LIB"])
 from f2cnn_amd import _lib
 from f2cnn_amd.gammatone import filters
 import bench
