@@ -133,7 +133,7 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
         for (int i = 0; i < ITER; ++i) {
             const int bf = tid + i * NT;
 #ifdef F2_KO_LDS
-            if (bf < 0) {
+            if constexpr (false) {
 #else
             if (FULL || bf < NB) {
 #endif
@@ -209,7 +209,7 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
                 }
             }
 #ifdef F2_KO_LDS
-            if (bf < 0) {
+            if constexpr (false) {
 #else
             if constexpr (!DST_REGS) {
 #endif

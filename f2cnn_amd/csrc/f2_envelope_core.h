@@ -229,20 +229,23 @@ __device__ __forceinline__ void lowpass_pairs_store(const F (&er)[NBLK], const F
     }
     __syncthreads();
     double ycarry = 0.0;                                           // true y at the end of the previous block
+    const F glf = (F)gl, gtf = (F)gt;
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) {
-        const double cw = cwl[jj * NW + wv];
-        const double sin_ = fma(gl, cw, (double)sc[jj]);           // zero-state value at the end of this pair
-        const double up = dpp_mov<0x138, 0xF>(sin_);               // wave_shr:1
-        const double sprev = lane > 0 ? up : cw;                   // ... at the end of the previous pair
-        const double y0 = fma(q, fma(gt, ycarry, sprev), (double)u0[jj]);
-        const double y1 = fma(q, y0, (double)u1[jj]);
+        // the carries into the wave (cw) and into the block (ycarry) were accumulated in float64; from here on the
+        // values are combined in F: they are sums of non-negative terms of the size of the output itself
+        const F cw = (F)cwl[jj * NW + wv];
+        const F sin_ = glf * cw + sc[jj];                          // zero-state value at the end of this pair
+        const F up = dpp_mov<0x138, 0xF>(sin_);                    // wave_shr:1
+        const F sprev = lane > 0 ? up : cw;                        // ... at the end of the previous pair
+        const F y0 = qf * (gtf * (F)ycarry + sprev) + u0[jj];
+        const F y1 = qf * y0 + u1[jj];
         const int i0 = 2 * (tid + NT * jj);
         if (pairs_ok) {
-            if (i0 < n) *reinterpret_cast<double2*>(y + i0) = make_double2(y0, y1);
+            if (i0 < n) *reinterpret_cast<double2*>(y + i0) = make_double2((double)y0, (double)y1);
         } else {
-            if (i0 < n) y[i0] = y0;
-            if (i0 + 1 < n) y[i0 + 1] = y1;
+            if (i0 < n) y[i0] = (double)y0;
+            if (i0 + 1 < n) y[i0 + 1] = (double)y1;
         }
         ycarry = fma(gblk, ycarry, btot[jj]);
     }
