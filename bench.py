@@ -15,6 +15,7 @@ For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank proce
 the MAX-reduction of the elapsed time. Rank 0 prints one JSON line.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -200,8 +201,9 @@ def main():
         # HBM bytes per launch from the PMC counters (collected separately with rocprofv3 --pmc and committed
         # under profiles/; only valid for the batch it was measured on)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_c_traffic_cfg3.json")
-        if args.workload == "cfg3" and os.path.exists(tpath):
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_cfg3.json")))   # latest measurement
+        tpath = tfiles[-1] if tfiles else ""
+        if args.workload == "cfg3" and tpath:
             tj = json.load(open(tpath))
             if tj.get("batch") == B and kname in tj and C == 128 and N == FS and args.fft == "f32":
                 traffic = tj[kname]["hbm_bytes_per_launch"]
