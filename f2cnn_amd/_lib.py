@@ -4,7 +4,9 @@ There is no CPU fallback: if the library is missing it is built with hipcc; if t
 gfx950 device is present when a context is requested, an exception is raised.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -67,6 +69,29 @@ def library_path():
     return _build.LIB_PATH
 
 
+def _share_hip_runtime_with_torch():
+    """A process can hold one HIP runtime. PyTorch-ROCm ships its own libamdhip64.so.7 (same SONAME as the system
+    one this library is linked against), and whichever loads first serves both: with the system runtime loaded first,
+    a later `import torch` (bench.py's process group, `cnn train`) finds no usable device. So when torch is installed
+    its runtime is mapped first, whatever the import order. F2CNN_HIP_RUNTIME=system skips this."""
+    if os.environ.get("F2CNN_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load(build_if_missing=True):
     """dlopen the library (building it first if it is absent) and declare every signature."""
     global _lib
@@ -78,6 +103,7 @@ def load(build_if_missing=True):
             if not build_if_missing:
                 raise FileNotFoundError(f"{path} is missing: run `python -m f2cnn_amd.build` (needs hipcc)")
             _build.build_library()
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

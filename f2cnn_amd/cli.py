@@ -6,17 +6,18 @@ package implements:
     python -m f2cnn_amd prepare label                       (needs the VTR .FB and TIMIT .PHN side files)
     python -m f2cnn_amd prepare input [--cutoff HZ] [--label/-l CSV] [--input/-i NPY]
     python -m f2cnn_amd prepare features [--cutoff HZ]     (filter + envelope in one pass, not in the reference)
+    python -m f2cnn_amd cnn train [--input/-i NPY] [--label/-l CSV]   (PyTorch-ROCm autograd; weights -> last_trained_model)
     python -m f2cnn_amd cnn eval --file/-f WAV [--lpf HZ] [--model/-m NPZ]
     python -m f2cnn_amd cnn evalnoise --file/-f WAV --noise/-n SNRdB [--lpf HZ] [--model/-m NPZ]
     python -m f2cnn_amd cnn evalrand [--count/-c N] [--lpf HZ] [--model/-m NPZ]
     python -m f2cnn_amd --configure            (writes configF2CNN.conf with the reference's defaults)
 
-organize / train / plot need the licensed TIMIT+VTR corpora or Keras and stay with the reference.
+organize / plot need the licensed TIMIT+VTR corpora or matplotlib and stay with the reference.
 """
 import argparse
 
 PREPARE = ("filter", "envelope", "label", "input", "features")
-CNN = ("eval", "evalnoise", "evalrand")
+CNN = ("train", "eval", "evalnoise", "evalrand")
 
 
 def build_parser():
@@ -32,6 +33,8 @@ def build_parser():
     p.add_argument('--label', '-l', dest='labelFile', nargs='?')
     c = sub.add_parser('cnn', help='CNN commands')
     c.add_argument('--file', '-f', dest='file', nargs='?')
+    c.add_argument('--input', '-i', dest='inputFile', nargs='?')
+    c.add_argument('--label', '-l', dest='labelFile', nargs='?')
     c.add_argument('--model', '-m', dest='model', nargs='?')
     c.add_argument('cnn_command', choices=CNN)
     c.add_argument('--lpf', action='store', type=int, dest='CUTOFF', help="low pass filter the envelopes")
@@ -64,6 +67,19 @@ def main(argv=None):
             from .scripts.processing.InputGenerator import GenerateInputData as fn
         fn(**kwargs)
     elif 'cnn_command' in args:
+        if args.cnn_command == 'train':                        # f2cnn.py:126-143
+            import os
+            from .scripts.CNN.Training import TrainAndPlotLoss
+            inputFile = args.inputFile or args.file or os.path.join('trainingData', 'last_input_data.npy')
+            labelFile = args.labelFile or os.path.join('trainingData', 'label_data.csv')
+            if not os.path.isfile(inputFile):
+                print("Please first generate the input data file with 'prepare input', or give one with --input")
+                return 1
+            if not os.path.isfile(labelFile):
+                print("Please first generate a label data file with 'prepare label', or give one with --label")
+                return 1
+            TrainAndPlotLoss(labelFile=labelFile, inputFile=inputFile)
+            return 0
         from .scripts.CNN import Evaluating
         kwargs = {}
         if args.CUTOFF is not None:                            # f2cnn.py:149-151

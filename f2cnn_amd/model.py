@@ -8,6 +8,8 @@ exists here, so weights travel as an ``.npz`` holding the 12 tensors in their Ke
 A PyTorch ``state_dict`` (Conv2d OIHW / Linear (out,in), NCHW flatten) is converted by
 ``F2CNNModel.from_torch_state_dict``. The forward pass itself is HIP kernel K4 (``f2_cnn_forward``).
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -64,13 +66,17 @@ class F2CNNModel:
 
     @classmethod
     def load(cls, path):
+        if not os.path.exists(path) and os.path.exists(str(path) + ".npz"):
+            path = str(path) + ".npz"
         z = np.load(path)
         rows = int(z["rows"]) if "rows" in z else 11
         channels = int(z["channels"]) if "channels" in z else 128
         return cls({k: z[k] for k in tensor_shapes(rows, channels)}, rows, channels)
 
     def save(self, path):
-        np.savez(path, rows=self.rows, channels=self.channels, **self.tensors)
+        """Writes exactly `path` (no .npz appended), so 'last_trained_model' keeps the reference's file name."""
+        with open(path, "wb") as fp:
+            np.savez(fp, rows=self.rows, channels=self.channels, **self.tensors)
 
     @classmethod
     def from_torch_state_dict(cls, sd, rows=11, channels=128):
