@@ -51,47 +51,19 @@ Dims make_dims(int rows, int channels) {
     return d;
 }
 
-// ---- conv1: 1 input channel, plain VALU. One thread = one pixel, all 32 output channels. ----
-__global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ x, const float* __restrict__ w,
-                                               const float* __restrict__ bias, float* __restrict__ out, int H, int W,
-                                               int64_t npix) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npix) return;
-    const int xx = (int)(p % W);
-    const int64_t t = p / W;
-    const int yy = (int)(t % H);
-    const float* img = x + (t - yy) * W;  // start of this window
-    float v[9];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int y2 = yy + dy - 1, x2 = xx + dx - 1;
-            v[dy * 3 + dx] = (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) ? img[(int64_t)y2 * W + x2] : 0.f;
-        }
-    float* o = out + p * C1;
-#pragma unroll
-    for (int co = 0; co < C1; co += 4) {
-        float4 r;
-        float* rp = &r.x;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float acc = 0.f;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) acc = fmaf(v[tap], w[tap * C1 + co + q], acc);
-            rp[q] = fmaxf(acc + bias[co + q], 0.f);
-        }
-        *reinterpret_cast<float4*>(o + co) = r;
-    }
-}
-
-// ---- conv2..4: implicit GEMM on v_mfma_f32_32x32x2_f32 ----
+// ---- conv2..4 (conv1 folded into conv2's staging): implicit GEMM on v_mfma_f32_32x32x2_f32 ----
 // NSPLIT waves share one task (one patch): each takes COUT/32/NSPLIT of the output tiles, so a 64-channel layer
 // keeps twice the waves per CU for the same LDS.
-template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT>
+// FUSE1 (conv2 only): `in` is the raw (n, Hin, Win) window tensor and the patch is *computed* - conv1 ('same', one input
+// channel, ReLU) evaluated for the 4 x 34 patch pixels from a 6 x 36 input region - instead of being read back from a
+// conv1 activation tensor: 180 KB per window less to write and 2.1x that less to stage.
+template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT, bool FUSE1 = false>
 __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __restrict__ in, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             int Hin, int Win, int64_t nwin) {
+                                                             int Hin, int Win, int64_t nwin,
+                                                             const float* __restrict__ w1 = nullptr,
+                                                             const float* __restrict__ b1 = nullptr) {
+    static_assert(!FUSE1 || (CIN == C1 && NSPLIT == 1 && !SAME), "the fused first layer feeds conv2");
     constexpr int PS = CIN + 4;           // LDS pitch per pixel: 16-byte aligned and conflict-free for ds_read_b128
     constexpr int PATCH = 4 * PW * PS;    // floats per wave
     constexpr int NT = COUT / 32 / NSPLIT;   // output tiles of this wave
@@ -120,6 +92,44 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     const int64_t win = t2 / row_pairs;
     const int y0 = 2 * rp, x0 = 32 * xt;
 
+    if constexpr (FUSE1) {
+        constexpr int XW = PW + 2;                                   // 36 input columns, 6 input rows
+        float* xin = lds_all + TPB * PATCH + (wave / NSPLIT) * (6 * XW);
+        const float* img1 = in + win * (int64_t)Hin * Win;
+        for (int e = lane; e < 6 * XW; e += 64) {
+            const int r6 = e / XW, p6 = e - r6 * XW;
+            const int yi = y0 - 1 + r6, xi = x0 - 1 + p6;
+            xin[e] = (yi >= 0 && yi < Hin && xi >= 0 && xi < Win) ? img1[(int64_t)yi * Win + xi] : 0.f;
+        }
+        // lane = (channel quad c4, pixel group pg): 4 channels of the pixels pg, pg + 8, ... (17 of the 136)
+        const int c4 = lane & 7, pg = lane >> 3;
+        float wr[9][4], br[4];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wr[tap][q] = w1[tap * C1 + c4 * 4 + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) br[q] = b1[c4 * 4 + q];
+        __syncthreads();
+#pragma unroll 1
+        for (int e = pg; e < 4 * PW; e += 8) {
+            const int r = e / PW, p = e - r * PW;
+            float xv[9];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) xv[dy * 3 + dx] = xin[(r + dy) * XW + p + dx];
+            float o4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float acc = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acc = fmaf(xv[tap], wr[tap][q], acc);   // same order as the oracle's conv1
+                o4[q] = fmaxf(acc + br[q], 0.f);
+            }
+            *reinterpret_cast<float4*>(patch + e * PS + c4 * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        }
+    } else {
     // stage the 4 x 34 x CIN patch with 16-byte loads (zero outside the image: 'same' padding / tile overhang)
     const float* img = in + win * (int64_t)Hin * Win * CIN;
 #pragma unroll 4
@@ -129,9 +139,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
         const int p = rem / C4, c4 = rem - p * C4;
         const int yi = y0 - PAD + r, xi = x0 - PAD + p;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef F2_KO_CNN_STAGE
         if (yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
             v = *reinterpret_cast<const float4*>(img + ((int64_t)yi * Win + xi) * CIN + c4 * 4);
+#endif
         *reinterpret_cast<float4*>(patch + (r * PW + p) * PS + c4 * 4) = v;
+    }
     }
     __syncthreads();
 
@@ -160,7 +173,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
             const float4 a1 = *reinterpret_cast<const float4*>(pa + PW * PS + 4 * q);
             float4 b[NT];
 #pragma unroll
+#ifdef F2_KO_CNN_B   // timing experiment (tools/build_variant.sh): one weight load per tap instead of per four steps
+            for (int nt = 0; nt < NT; ++nt) b[nt] = pb[nt * 32];
+#else
             for (int nt = 0; nt < NT; ++nt) b[nt] = pb[(int64_t)q * COUT + nt * 32];
+#endif
             const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -174,6 +191,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
         }
     }
 
+#ifdef F2_KO_CNN_STORE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     if (!live) return;
     float* o = out + win * (int64_t)Hout * Wout * COUT;
 #pragma unroll
@@ -305,8 +325,9 @@ __global__ __launch_bounds__(256) void k_dense2_softmax(const float* __restrict_
     if (labels) labels[i] = s1 > s0 ? 1 : 0;   // ties -> 0 ("falling"), Evaluating.py:87
 }
 
-template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT>
-int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, float* out, int Hin, int Win, int64_t n) {
+template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT, bool FUSE1 = false>
+int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, float* out, int Hin, int Win, int64_t n,
+                const float* w1 = nullptr, const float* b1 = nullptr) {
     const int Ho = SAME ? Hin : Hin - 2, Wo = SAME ? Win : Win - 2;
     const int row_pairs = POOL ? Ho / 2 : (Ho + 1) / 2;
     const int wneed = POOL ? (Wo / 2) * 2 : Wo;
@@ -314,13 +335,13 @@ int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, fl
     const int64_t tasks = n * row_pairs * xtiles;
     if (tasks <= 0) return F2_OK;
     constexpr int TPB = WAVES / NSPLIT;
-    constexpr size_t lds = sizeof(float) * TPB * 4 * PW * (CIN + 4);
-    auto kern = k_conv3x3_mfma<CIN, COUT, SAME, POOL, WAVES, NSPLIT>;
+    constexpr size_t lds = sizeof(float) * TPB * (4 * PW * (CIN + 4) + (FUSE1 ? 6 * (PW + 2) : 0));
+    auto kern = k_conv3x3_mfma<CIN, COUT, SAME, POOL, WAVES, NSPLIT, FUSE1>;
     if (lds > 64 * 1024)
         F2_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t blocks = (tasks + TPB - 1) / TPB;
     F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, ctx->stream, in, w, b, out, Hin, Win, n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, ctx->stream, in, w, b, out, Hin, Win, n, w1, b1);
     F2_HIP(ctx, hipGetLastError());
     return F2_OK;
 }
@@ -329,24 +350,20 @@ int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, fl
 
 size_t f2_cnn_workspace_floats(const f2_cnn* cnn) {
     const Dims d = make_dims(cnn->rows, cnn->channels);
-    return (size_t)d.H1 * d.W1 * C1 + (size_t)d.Hp1 * d.Wp1 * C2 + (size_t)d.Hp1 * d.Wp1 * C3 + (size_t)d.flat + D1;
+    return (size_t)d.Hp1 * d.Wp1 * C2 + (size_t)d.Hp1 * d.Wp1 * C3 + (size_t)d.flat + D1;   // conv1's output never exists
 }
 
 int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_ws, float* d_scores,
                   uint8_t* d_labels) {
     if (n <= 0) return F2_OK;
     const Dims d = make_dims(cnn->rows, cnn->channels);
-    float* a1 = d_ws;
-    float* a2 = a1 + (size_t)n * d.H1 * d.W1 * C1;
+    float* a2 = d_ws;
     float* a3 = a2 + (size_t)n * d.Hp1 * d.Wp1 * C2;
     float* a4 = a3 + (size_t)n * d.Hp1 * d.Wp1 * C3;
     float* a5 = a4 + (size_t)n * d.flat;
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
-    const int64_t npix = n * d.H1 * d.W1;
-    hipLaunchKernelGGL(k_conv1, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, d_x, cnn->t(0), cnn->t(1),
-                       a1, d.H1, d.W1, npix);
-    F2_HIP(ctx, hipGetLastError());
-    F2_TRY((launch_conv<C1, C2, false, true, 4, 1>(ctx, a1, cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n)));
+    // conv1 is evaluated inside conv2's patch staging
+    F2_TRY((launch_conv<C1, C2, false, true, 4, 1, true>(ctx, d_x, cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n, cnn->t(0), cnn->t(1))));
     F2_TRY((launch_conv<C2, C3, true, false, 8, 2>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
     F2_TRY((launch_conv<C3, C4, false, true, 4, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
     {
