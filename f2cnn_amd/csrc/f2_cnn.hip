@@ -11,12 +11,14 @@
 // their Keras layouts: a (3,3,Cin,Cout) HWIO kernel flattened is exactly the K x N operand
 // (k = (dy*3+dx)*Cin + ci). Activations are NHWC in HBM between layers, processed in chunks of windows.
 //
-// Implicit-GEMM tile: one wavefront = 2 output rows x 32 output columns x all Cout of one window.
-// Its 4 x 34 x Cin input patch is staged in LDS with a (Cin+1)-float pitch per pixel, so the MFMA A
-// operand (lane = pixel, one k per half-wave) is a conflict-free ds_read_b32; the B operand (lane = Cout)
-// is a coalesced weight row. ReLU, bias and the 2x2 max-pool are applied from the accumulators: the
-// 32x32 accumulator keeps pixel pairs (2t, 2t+1) in one lane, and the second pooled row is the wave's
-// second M-tile, so pooling needs no cross-lane traffic.
+// Implicit-GEMM tile: one task = 2 output rows x 32 output columns of one window; its 4 x 34 x Cin input patch sits in
+// LDS at a (Cin+4)-float pitch per pixel (16-byte aligned, conflict-free for ds_read_b128). MFMA step s multiplies
+// channel s (half-wave 0) and channel Cin/2 + s (half-wave 1), so four steps are one 16-byte LDS read of the patch
+// (A operand, lane = pixel) and one 16-byte load of the re-laid-out weights wt[tap][h][s/4][cout][s%4] (B operand,
+// lane = Cout); both are requested one step ahead of the MFMAs that use them. ReLU, bias and the 2x2 max-pool are
+// applied from the accumulators: the 32x32 accumulator keeps pixel pairs (2t, 2t+1) in one lane, and the second
+// pooled row is the wave's second M-tile, so pooling needs no cross-lane traffic. conv1 has no kernel of its own:
+// conv2's staging evaluates it (FUSE1 below).
 #include "f2_internal.h"
 
 namespace {
@@ -162,33 +164,40 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     const int i = lane & 31, h = lane >> 5;
     const float* pa0 = patch + i * PS + h * HALF;
     const float4* wq = reinterpret_cast<const float4*>(w) + (int64_t)h * (HALF / 4) * COUT + ns * NT * 32 + i;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap % 3;
+    // The (tap, q) steps are software pipelined: the A (LDS) and B (weights) operands of step it+1 are requested before
+    // the eight MFMAs of step it are issued, so their latency hides behind 512 cycles of matrix-core time instead of
+    // stalling the wave after them (an MFMA occupies the pipe for 64 cycles; the loads used to trail the last one).
+    constexpr int QN = HALF / 4, NIT = 9 * QN;
+    float4 av0[2], av1[2], bq[2][NT];
+    auto fetch = [&](int it, int buf) {
+        const int tap = it / QN, q = it - tap * QN;
+        const int dy = tap / 3, dx = tap - dy * 3;
         const float* pa = pa0 + (dy * PW + dx) * PS;
-        const float4* pb = wq + (int64_t)tap * 2 * (HALF / 4) * COUT;
+        const float4* pb = wq + (int64_t)tap * 2 * QN * COUT;
+        av0[buf] = *reinterpret_cast<const float4*>(pa + 4 * q);
+        av1[buf] = *reinterpret_cast<const float4*>(pa + PW * PS + 4 * q);
 #pragma unroll
-        for (int q = 0; q < HALF / 4; ++q) {
-            const float4 a0 = *reinterpret_cast<const float4*>(pa + 4 * q);
-            const float4 a1 = *reinterpret_cast<const float4*>(pa + PW * PS + 4 * q);
-            float4 b[NT];
+        for (int nt = 0; nt < NT; ++nt) bq[buf][nt] = pb[(int64_t)q * COUT + nt * 32];
+    };
+    fetch(0, 0);
 #pragma unroll
-#ifdef F2_KO_CNN_B   // timing experiment (tools/build_variant.sh): one weight load per tap instead of per four steps
-            for (int nt = 0; nt < NT; ++nt) b[nt] = pb[nt * 32];
-#else
-            for (int nt = 0; nt < NT; ++nt) b[nt] = pb[(int64_t)q * COUT + nt * 32];
-#endif
-            const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+    for (int it = 0; it < NIT; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < NIT) fetch(it + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float a0v[4] = {av0[cur].x, av0[cur].y, av0[cur].z, av0[cur].w};
+        const float a1v[4] = {av1[cur].x, av1[cur].y, av1[cur].z, av1[cur].w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float bv = r == 0 ? b[nt].x : r == 1 ? b[nt].y : r == 2 ? b[nt].z : b[nt].w;
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[r], bv, acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[r], bv, acc[1][nt], 0, 0, 0);
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 bb = bq[cur][nt];
+                const float bv = r == 0 ? bb.x : r == 1 ? bb.y : r == 2 ? bb.z : bb.w;
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[r], bv, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[r], bv, acc[1][nt], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #ifdef F2_KO_CNN_STORE
