@@ -136,6 +136,9 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     for (auto& prec : ctx->tw_large)
         for (f2_scratch& s : prec)
             if (s.ptr) (void)hipFree(s.ptr);
+    for (f2_scratch& s : ctx->tw_split)
+        if (s.ptr) (void)hipFree(s.ptr);
+    if (ctx->work3.ptr) (void)hipFree(ctx->work3.ptr);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

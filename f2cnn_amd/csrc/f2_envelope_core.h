@@ -132,10 +132,12 @@ constexpr size_t lowpass_lds_bytes() {
     return sizeof(F) * NBLK * NT + sizeof(double) * (2 * NBLK * (NT / 64) + NBLK);
 }
 
+// y_in / e_in: filter state entering the first sample (y[-1], e[-1]); the return value is y of the last of the
+// 2*NT*NBLK samples (rows longer than that are filtered segment by segment, f2_envelope_split.hip).
 template <typename F, int NT, int NBLK>
-__device__ __forceinline__ void lowpass_pairs_store(const F (&er)[NBLK], const F (&ei)[NBLK], double a1, double b0,
-                                                    unsigned char* smem, double* __restrict__ y, int n, bool pairs_ok,
-                                                    int tid) {
+__device__ __forceinline__ double lowpass_pairs_store(const F (&er)[NBLK], const F (&ei)[NBLK], double a1, double b0,
+                                                      unsigned char* smem, double* __restrict__ y, int n, bool pairs_ok,
+                                                      int tid, double y_in = 0.0, F e_in = F(0)) {
     constexpr int NW = NT / 64;
     static_assert(NBLK <= NT, "one thread per block chains the wave totals");
     F* e1s = reinterpret_cast<F*>(smem);                           // [NBLK][NT] odd samples, for e[n-1]
@@ -178,7 +180,7 @@ __device__ __forceinline__ void lowpass_pairs_store(const F (&er)[NBLK], const F
     F u0[NBLK], u1[NBLK], sc[NBLK];
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) {
-        const F eprev = tid > 0 ? e1s[jj * NT + tid - 1] : (jj > 0 ? e1s[(jj - 1) * NT + NT - 1] : F(0));
+        const F eprev = tid > 0 ? e1s[jj * NT + tid - 1] : (jj > 0 ? e1s[(jj - 1) * NT + NT - 1] : e_in);
         u0[jj] = b0f * (er[jj] + eprev);
         u1[jj] = b0f * (ei[jj] + er[jj]);
         sc[jj] = u1[jj] + qf * u0[jj];
@@ -228,7 +230,7 @@ __device__ __forceinline__ void lowpass_pairs_store(const F (&er)[NBLK], const F
         btot[tid] = c;
     }
     __syncthreads();
-    double ycarry = 0.0;                                           // true y at the end of the previous block
+    double ycarry = y_in;                                          // true y at the end of the previous block
     const F glf = (F)gl, gtf = (F)gt;
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) {
@@ -249,6 +251,7 @@ __device__ __forceinline__ void lowpass_pairs_store(const F (&er)[NBLK], const F
         }
         ycarry = fma(gblk, ycarry, btot[jj]);
     }
+    return ycarry;
 }
 
 }  // namespace f2fft

@@ -34,6 +34,8 @@ struct f2_ctx {
     f2_scratch xbuf;       // window tensor chunk between K3 and K4
     f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
     f2_scratch tw_large[2][24];   // same for the global-memory transform of long rows
+    f2_scratch tw_split[24];      // tables of the four-step transform (f2_envelope_split.hip), by log2 H
+    f2_scratch work3;             // utterance lists of the four-step launches
     std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
     std::vector<double> coefs_host;     // what ctx->coefs currently holds
     bool prof_on = false;
@@ -85,6 +87,10 @@ int f2_prof_begin(f2_ctx* ctx, int kernel_id);
 int f2_prof_end(f2_ctx* ctx, int kernel_id);
 
 // longest row (2^22 samples = 262 s at 16 kHz) the global-memory envelope path accepts
+// rows between the LDS limit and 262144 samples: four-step transform with LDS-resident 4096-point parts
+bool f2_envelope_split_supports(int log2h, int precision);
+int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets, const int* utts,
+                             int nutt, int log2h, int C, int lpf, double b0, double a1);
 #define F2_MAX_LOG2M_LARGE 22
 int f2_launch_envelope_large(f2_ctx* ctx, const double* d_x, double* d_y, int64_t n, int C, int lpf, double b0,
                              double a1, int precision);

@@ -49,11 +49,14 @@ def test_fft32_longest_rows(N):
         assert chan_relerr(EE.ExtractEnvelopeFromMatrix(m, lpf, 50, precision=_lib.FFT_F32), ref) <= TOL
 
 
-@pytest.mark.parametrize("N,precision,tol", [(40000, _lib.FFT_F32, TOL), (48000, _lib.FFT_F32, TOL), (65536, _lib.FFT_F32, TOL),
-                                             (70001, _lib.FFT_F32, TOL), (20000, _lib.FFT_F64, TOL_F64),
+@pytest.mark.parametrize("N,precision,tol", [(32769, _lib.FFT_F32, TOL), (40000, _lib.FFT_F32, TOL), (48000, _lib.FFT_F32, TOL),
+                                             (65536, _lib.FFT_F32, TOL), (70001, _lib.FFT_F32, TOL),
+                                             (131073, _lib.FFT_F32, TOL), (262144, _lib.FFT_F32, TOL),
+                                             (262145, _lib.FFT_F32, TOL), (20000, _lib.FFT_F64, TOL_F64),
                                              (50000, _lib.FFT_F64, TOL_F64)])
-def test_long_rows_global_memory_path(N, precision, tol):
-    # TIMIT sentences are 1-8 s: rows beyond the LDS-resident transform take the global-memory path
+def test_long_rows_beyond_lds(N, precision, tol):
+    # TIMIT sentences are 1-8 s. float transforms of 32769..262144 samples run as four-step FFTs (H1 = 8, 16, 32 times
+    # LDS-resident 4096-point parts); longer rows and float64 transforms take the global-memory radix-16 passes
     m = np.random.default_rng(N).standard_normal((3, N)) * np.array([[1.0], [3000.0], [1e-3]])
     for lpf in (False, True):
         ref = orc.extract_envelope_from_matrix(m, lpf, 50)
@@ -63,10 +66,11 @@ def test_long_rows_global_memory_path(N, precision, tol):
 
 def test_mixed_short_and_long_batch():
     rng = np.random.default_rng(77)
-    mats = [rng.standard_normal((4, n)) for n in (16000, 50000, 1000, 33000)]
-    outs = EE.ExtractEnvelopesFromMatrices(mats, True, 50)
-    for m, o in zip(mats, outs):
-        assert chan_relerr(o, orc.extract_envelope_from_matrix(m, True, 50)) <= TOL
+    mats = [rng.standard_normal((4, n)) for n in (16000, 50000, 1000, 33000, 70000, 49999, 140001)]
+    for lpf, cutoff in ((True, 50), (False, 50), (True, 5)):      # 5 Hz: the filter state decays over many segments
+        outs = EE.ExtractEnvelopesFromMatrices(mats, lpf, cutoff)
+        for m, o in zip(mats, outs):
+            assert chan_relerr(o, orc.extract_envelope_from_matrix(m, lpf, cutoff)) <= TOL, (m.shape, lpf, cutoff)
 
 
 def test_on_filterbank_output_cfg1():

@@ -9,7 +9,7 @@ from f2cnn_amd import _lib
 from f2cnn_amd.scripts.processing import EnvelopeExtraction as EE
 from oracle import f2cnn_oracle as orc
 
-for n in (1500, 3000, 8000, 16000, 16384, 30000):
+for n in (1500, 3000, 8000, 16000, 16384, 30000, 40000, 70001, 140000):
     wav = orc.synth_utterance(n, n)
     gfb = orc.erb_filterbank(wav, orc.make_erb_filters(16000, orc.centre_freqs(16000, 128, 100)))
     for lpf in (False, True):
