@@ -449,14 +449,14 @@ constexpr int MAX_LOG2H_F64 = 13;  // rows up to 16384 samples
 bool f2_envelope_accepts_f32(const int64_t* h_offsets, int B, int precision) {
     if (precision != F2_FFT_F32) return false;
     for (int b = 0; b < B; ++b)
-        if (h_offsets[b + 1] - h_offsets[b] > (int64_t(2) << 13)) return false;   // KEEP_X kernels only (LOG2H <= 13)
+        if (h_offsets[b + 1] - h_offsets[b] > (int64_t(2) << 14)) return false;   // kernels that keep x in registers (LOG2H <= 14)
     return true;
 }
 
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
                        int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, bool f32_in) {
     F2_CHECK(ctx, !f32_in || f2_envelope_accepts_f32(h_offsets, B, precision), F2_ERR_INVALID,
-             "float32 hand-off needs the float FFT and rows of at most 16384 samples");
+             "float32 hand-off needs the float FFT and rows of at most 32768 samples");
     EnvParams P;
     P.f32_in = f32_in ? 1 : 0;
     P.stamps = nullptr;
@@ -533,7 +533,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         if (g.empty()) continue;
         P.ulist = identity ? nullptr : d_lists + pos;
         pos += g.size();
-        const int nthreads = log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
+        const int nthreads = (log2h == 14 && precision == F2_FFT_F32) ? 1024 : log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
         const dim3 grid((unsigned)(g.size() * (size_t)C)), block(nthreads);
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
         if (precision == F2_FFT_F32) {

@@ -13,16 +13,16 @@ namespace f2fft {
 #endif
 // threads per workgroup: 256, or 512 where 256 threads would need more than 256 registers each
 template <typename F, int LOG2H>
-constexpr int threads_for() { return LOG2H >= 13 ? 512 : 256; }
+constexpr int threads_for() { return (LOG2H == 14 && sizeof(F) == 4) ? 1024 : LOG2H >= 13 ? 512 : 256; }
 // waves per SIMD the register allocator must leave room for (2 workgroups per CU wherever LDS allows)
 template <typename F, int LOG2H>
 constexpr int min_waves_for() {
-    return (sizeof(F) == 4 && LOG2H == 13) ? 4 : (sizeof(F) == 4 && LOG2H <= 12) ? 2 : (sizeof(F) == 8 && LOG2H <= 12) ? 2 : 2;
+    return (sizeof(F) == 4 && (LOG2H == 13 || LOG2H == 14)) ? 4 : (sizeof(F) == 4 && LOG2H <= 12) ? 2 : (sizeof(F) == 8 && LOG2H <= 12) ? 2 : 2;
 }
 
 // Whether pass 0 derives its 15 twiddles per butterfly from two loaded ones (radix-16 first pass, float transforms)
 template <typename F, int LOG2H>
-constexpr bool derive_tw0() { return sizeof(F) == 4 && LOG2H >= 11 && LOG2H <= 13; }
+constexpr bool derive_tw0() { return sizeof(F) == 4 && LOG2H >= 11 && LOG2H <= 14; }
 
 // Whether the Hilbert pair step is folded into the inverse transform's first pass (needs ~3x the pass's points in
 // registers for a moment: only where the register budget allows) or runs as its own sweep over LDS.
@@ -31,14 +31,16 @@ constexpr bool fuse_hilbert() { return LOG2H >= 1 && LOG2H <= 12 && sizeof(F) ==
 
 // ---- radix plan: symmetric (first radix == last radix), radices 2..32 ----
 // H = 8192 (the 1 s / 16 kHz row) runs as 16-8-4-16 on 512 threads: 16 points per thread in every pass keeps
-// the kernel under 128 registers, i.e. 16 waves per CU to hide LDS / barrier / HBM latency.
+// the kernel under 128 registers, i.e. 16 waves per CU to hide LDS / barrier / HBM latency. H = 16384 does the same
+// with 16-16-4-16 on 1024 threads (one workgroup per CU by LDS, still 16 waves).
 constexpr int plan_npass(int h) {
-    return h == 0 ? 0 : h <= 5 ? 1 : h <= 10 ? ((h & 1) ? 3 : 2) : (h == 13 && F2_PLAN13_PASSES == 4) ? 4 : 3;
+    return h == 0 ? 0 : h <= 5 ? 1 : h <= 10 ? ((h & 1) ? 3 : 2) : (h == 13 && F2_PLAN13_PASSES == 4) ? 4 : h == 14 ? 4 : 3;
 }
 constexpr int plan_bits(int h, int pass) {
     if (h <= 5) return h;
     if (h <= 10) return (h & 1) ? (pass == 1 ? 1 : (h - 1) / 2) : h / 2;
     if (h == 13 && F2_PLAN13_PASSES == 4) return pass == 1 ? 3 : pass == 2 ? 2 : 4;
+    if (h == 14) return pass == 2 ? 2 : 4;   // 16-16-4-16 on 1024 threads: 16 points per thread, as for h == 13
     const int a = h <= 13 ? 4 : 5;
     return pass == 1 ? h - 2 * a : a;
 }

@@ -11,7 +11,8 @@ C = 128
 TOTAL = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000      # samples per batch
 ctx = _lib.Context(0)
 coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
-for n in (8000, 16000, 16384, 24000, 32768, 40000, 48000, 65536, 80000, 131072):
+LENGTHS = [int(a) for a in sys.argv[2:]] or [8000, 16000, 16384, 24000, 32768, 40000, 48000, 65536, 80000, 131072]
+for n in LENGTHS:
     B = max(1, TOTAL // n)
     waves = bench.synth_batch(7, 0, B, n)
     off = np.arange(B + 1, dtype=np.int64) * n
