@@ -231,8 +231,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
 }
 
 // ---- dense1: (n, K) x (K, 516) on the same MFMA ----
-// One 6-wave workgroup = 32 windows x 6 of the 17 output tiles (blockIdx.y picks the group, one tile per wave, so a
-// 4096-window chunk is 384 workgroups: enough to fill 256 CUs). K is walked in
+// One 6-wave workgroup = 64 windows (two M tiles) x 6 of the 17 output tiles (blockIdx.y picks the group, one output
+// tile per wave, every weight load feeds both M tiles). K is walked in
 // chunks of 64: the 32 x 64 activation chunk is staged in LDS (double buffered, 16-byte loads, pitch 68) and
 // read back as the A operand with ds_read_b128; the B operand comes from the re-laid-out weights
 // wt[chunk][h][q][n (padded to 544)][4], one 16-byte load per four MFMA steps.
@@ -240,19 +240,22 @@ constexpr int D1_TILES = (D1 + 31) / 32;   // 17
 constexpr int D1_NPAD = D1_TILES * 32;     // 544
 constexpr int D1_KC = 64;
 constexpr int D1_WAVES = 6;
+constexpr int D1_MT = 2;                   // M tiles (32 windows each) per workgroup: every weight load feeds 2 MFMA tiles
 __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __restrict__ a, const float* __restrict__ wt,
                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                int K, int64_t n) {
     constexpr int PS = D1_KC + 4;
-    constexpr int TPW = 1;                                       // tiles per wave
-    __shared__ __attribute__((aligned(16))) float As[2][32 * PS];
+    constexpr int ROWS = 32 * D1_MT;
+    __shared__ __attribute__((aligned(16))) float As[2][ROWS * PS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t w0 = (int64_t)blockIdx.x * 32;
+    const int64_t w0 = (int64_t)blockIdx.x * ROWS;
     const int i = lane & 31, h = lane >> 5;
     const int nchunks = K / D1_KC;
+    const int nt = blockIdx.y * D1_WAVES + wave;       // this wave's output tile
+    const bool live = nt < D1_TILES;
 
     auto stage = [&](int kc, int buf) {
-        for (int e = tid; e < 32 * (D1_KC / 4); e += D1_WAVES * 64) {
+        for (int e = tid; e < ROWS * (D1_KC / 4); e += D1_WAVES * 64) {
             const int row = e / (D1_KC / 4), c4 = e - row * (D1_KC / 4);
             const int64_t wr = w0 + row < n ? w0 + row : n - 1;
             *reinterpret_cast<float4*>(&As[buf][row * PS + c4 * 4]) =
@@ -260,9 +263,9 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __re
         }
     };
 
-    f32x16 acc[TPW];
+    f32x16 acc[D1_MT];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
+    for (int t = 0; t < D1_MT; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
@@ -271,40 +274,38 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __re
     for (int kc = 0; kc < nchunks; ++kc) {
         const int buf = kc & 1;
         if (kc + 1 < nchunks) stage(kc + 1, buf ^ 1);
-        const float* pa = &As[buf][i * PS + h * (D1_KC / 2)];
-        const float4* pb = reinterpret_cast<const float4*>(wt) + ((int64_t)(kc * 2 + h) * (D1_KC / 8)) * D1_NPAD + i;
+        if (live) {
+            const float* pa = &As[buf][i * PS + h * (D1_KC / 2)];
+            const float4* pb = reinterpret_cast<const float4*>(wt) + ((int64_t)(kc * 2 + h) * (D1_KC / 8)) * D1_NPAD + nt * 32 + i;
 #pragma unroll
-        for (int q = 0; q < D1_KC / 8; ++q) {
-            const float4 av = *reinterpret_cast<const float4*>(pa + 4 * q);
-            const float avv[4] = {av.x, av.y, av.z, av.w};
-            float4 bv[TPW];
+            for (int q = 0; q < D1_KC / 8; ++q) {
+                const float4 bv = pb[(int64_t)q * D1_NPAD];
+                float4 av[D1_MT];
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int nt = blockIdx.y * D1_WAVES + wave + t * D1_WAVES;
-                bv[t] = nt < D1_TILES ? pb[(int64_t)q * D1_NPAD + nt * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+                for (int t = 0; t < D1_MT; ++t) av[t] = *reinterpret_cast<const float4*>(pa + t * 32 * PS + 4 * q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    const float b = r == 0 ? bv.x : r == 1 ? bv.y : r == 2 ? bv.z : bv.w;
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    const float b = r == 0 ? bv[t].x : r == 1 ? bv[t].y : r == 2 ? bv[t].z : bv[t].w;
-                    if (blockIdx.y * D1_WAVES + wave + t * D1_WAVES < D1_TILES) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[r], b, acc[t], 0, 0, 0);
+                    for (int t = 0; t < D1_MT; ++t) {
+                        const float av_r = r == 0 ? av[t].x : r == 1 ? av[t].y : r == 2 ? av[t].z : av[t].w;
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_r, b, acc[t], 0, 0, 0);
+                    }
                 }
+            }
         }
         __syncthreads();
     }
+    const int col = nt * 32 + i;
+    if (live && col < D1) {
+        const float b = bias[col];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int nt = blockIdx.y * D1_WAVES + wave + t * D1_WAVES;
-        const int col = nt * 32 + i;
-        if (nt < D1_TILES && col < D1) {
-            const float b = bias[col];
+        for (int t = 0; t < D1_MT; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int64_t wr = w0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int64_t wr = w0 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (wr < n) out[wr * D1 + col] = fmaxf(acc[t][q] + b, 0.f);
             }
-        }
     }
 }
 
@@ -376,7 +377,7 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
     F2_TRY((launch_conv<C2, C3, true, false, 8, 2>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
     F2_TRY((launch_conv<C3, C4, false, true, 4, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
     {
-        hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((n + 31) / 32), (D1_TILES + D1_WAVES - 1) / D1_WAVES), dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8),
+        hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES), dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8),
                            cnn->t(9), a5, d.flat, n);
         F2_HIP(ctx, hipGetLastError());
     }
