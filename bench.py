@@ -157,9 +157,8 @@ def main():
         d_labels = ctx.malloc(nb * B)
 
         def step():
-            for u in range(B):
-                ctx.eval_utterance(hcnn, d_wave + 2 * N * u, _lib.WAVE_I16, N, coefs, C, False, 0.0, precision, 5, 160,
-                                   None, d_scores + 8 * nb * u, d_labels + nb * u, _lib.MEM_DEVICE)
+            ctx.eval_batch(hcnn, d_wave, _lib.WAVE_I16, offsets, coefs, B, C, False, 0.0, precision, 5, 160, d_scores,
+                           d_labels, _lib.MEM_DEVICE)
         # flop per CNN launch group: filled in from the measured number of launches (the library chunks the windows)
         algo = {"k_cnn_forward": None, "k_gather_windows": 0,
                 "k_erb_filterbank": 2 * N + 8 * C * N, "k_envelope": 16 * C * N}

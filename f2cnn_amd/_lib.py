@@ -53,6 +53,7 @@ SIGNATURES = {
     "f2_cnn_destroy": (_i, [_vp, _vp]),
     "f2_cnn_forward": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i]),
     "f2_eval_utterance": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _i, _i, _d, _i, _i, _i, _vp, _vp, _vp, _P(_i64), _i]),
+    "f2_eval_batch": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _d, _i, _i, _i, _vp, _vp, _i]),
 }
 
 _lib = None
@@ -248,6 +249,14 @@ class Context:
                                               _ptr(scores), _ptr(labels), C.byref(nb), mem_space))
         return nb.value
 
+
+    def eval_batch(self, handle, wave, wave_dtype, offsets, coefs, B, Cn, lpf, cutoff, precision, radius, step, scores,
+                   labels, mem_space):
+        """Ragged batch through filterbank, envelope, every-sample windows and the CNN; see f2_eval_batch."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.check(self.lib.f2_eval_batch(self.handle, handle, _ptr(wave), wave_dtype, _ptr(offsets), _ptr(coefs), int(B),
+                                          Cn, int(bool(lpf)), float(cutoff), precision, radius, step, _ptr(scores),
+                                          _ptr(labels), mem_space))
 
 _default_ctx = {}
 

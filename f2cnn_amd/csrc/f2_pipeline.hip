@@ -194,4 +194,96 @@ int f2_eval_utterance(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave
     return F2_OK;
 }
 
+int f2_eval_batch(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave_dtype, const int64_t* offsets,
+                  const double* coefs, int B, int C, int lpf, double cutoff_hz, int fft_precision, int radius, int step,
+                  float* scores_or_null, uint8_t* labels_or_null, int mem_space) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_HIP(ctx, hipSetDevice(ctx->device));
+    F2_CHECK(ctx, cnn && coefs && offsets, F2_ERR_INVALID, "null argument");
+    F2_CHECK(ctx, cnn->dev == ctx->device, F2_ERR_INVALID, "cnn weights live on device %d, context on %d", cnn->dev, ctx->device);
+    F2_CHECK(ctx, mem_space == F2_MEM_HOST || mem_space == F2_MEM_DEVICE, F2_ERR_INVALID, "bad mem_space %d", mem_space);
+    F2_CHECK(ctx, wave_dtype == F2_WAVE_I16 || wave_dtype == F2_WAVE_F64, F2_ERR_INVALID, "bad wave_dtype %d", wave_dtype);
+    F2_CHECK(ctx, fft_precision == F2_FFT_F32 || fft_precision == F2_FFT_F64, F2_ERR_INVALID, "bad fft_precision %d", fft_precision);
+    F2_CHECK(ctx, !lpf || (cutoff_hz > 0 && cutoff_hz < 8000), F2_ERR_INVALID, "cutoff %g Hz outside (0, 8000)", cutoff_hz);
+    F2_CHECK(ctx, B >= 0 && C > 0 && radius >= 0 && step >= 0, F2_ERR_INVALID, "bad size");
+    F2_CHECK(ctx, cnn->rows == 2 * radius + 1 && cnn->channels == C, F2_ERR_INVALID,
+             "network was built for %d x %d windows, asked for %d x %d", cnn->rows, cnn->channels, 2 * radius + 1, C);
+    F2_CHECK(ctx, offsets[0] == 0, F2_ERR_INVALID, "offsets[0] must be 0");
+    for (int b = 0; b < B; ++b)
+        F2_CHECK(ctx, offsets[b + 1] >= offsets[b], F2_ERR_INVALID, "offsets must not decrease (utterance %d)", b);
+    const int64_t total = B > 0 ? offsets[B] : 0;
+    if (total == 0) return F2_OK;
+    F2_CHECK(ctx, wave, F2_ERR_INVALID, "null wave");
+    const int R = 2 * radius + 1;
+    int64_t nb_total = 0, nb_max = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t nb = offsets[b + 1] - offsets[b] - (int64_t)R * step;   // Evaluating.py:73
+        if (nb > 0) {
+            nb_total += nb;
+            nb_max = nb > nb_max ? nb : nb_max;
+        }
+    }
+
+    // filterbank + envelope of the whole batch
+    F2_TRY(f2_upload_offsets(ctx, offsets, B));
+    F2_TRY(f2_upload_coefs(ctx, coefs, C));
+    F2_TRY(f2_reserve(ctx, ctx->stage_out, sizeof(double) * (size_t)C * (size_t)total));
+    double* d_env = (double*)ctx->stage_out.ptr;
+    const void* d_wave = wave;
+    if (mem_space == F2_MEM_HOST) {
+        const size_t wb = (wave_dtype == F2_WAVE_I16 ? 2 : 8) * (size_t)total;
+        F2_TRY(f2_reserve(ctx, ctx->stage_in, wb));
+        F2_HIP(ctx, hipMemcpyAsync(ctx->stage_in.ptr, wave, wb, hipMemcpyHostToDevice, ctx->stream));
+        d_wave = ctx->stage_in.ptr;
+    }
+    const bool f32_handoff = f2_envelope_accepts_f32(offsets, B, fft_precision);
+    F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
+                                (const double*)ctx->coefs.ptr, B, C, d_env, f32_handoff));
+    F2_TRY(f2_launch_envelope(ctx, d_env, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz, fft_precision,
+                              d_env, f32_handoff));
+    if (nb_total == 0) {
+        if (mem_space == F2_MEM_HOST) F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return F2_OK;
+    }
+
+    // every-sample windows -> normalise -> CNN, utterance by utterance, chunk by chunk; nothing leaves HBM
+    const int64_t chunk = nb_max < CNN_CHUNK ? nb_max : CNN_CHUNK;
+    F2_TRY(f2_reserve(ctx, ctx->xbuf, sizeof(float) * (size_t)chunk * R * (size_t)C));
+    F2_TRY(f2_reserve(ctx, ctx->work, sizeof(float) * f2_cnn_workspace_floats(cnn) * (size_t)chunk));
+    float* d_scores = scores_or_null;
+    uint8_t* d_labels = labels_or_null;
+    if (mem_space == F2_MEM_HOST) {
+        F2_TRY(f2_reserve(ctx, ctx->stage_aux, (sizeof(float) * 2 + 1) * (size_t)nb_total + 64));
+        d_scores = (float*)ctx->stage_aux.ptr;
+        d_labels = (uint8_t*)(d_scores + 2 * nb_total);
+    }
+    F2_TRY(reset_flag(ctx));
+    const int64_t reach = (int64_t)radius * step;
+    int64_t done = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t N = offsets[b + 1] - offsets[b];
+        const int64_t nb = N - (int64_t)R * step;
+        if (nb <= 0) continue;
+        const double* env_b = d_env + (size_t)C * (size_t)offsets[b];
+        for (int64_t s = 0; s < nb; s += chunk) {
+            const int64_t m = nb - s < chunk ? nb - s : chunk;
+            F2_TRY(f2_launch_gather(ctx, env_b, C, N, nullptr, reach + s, m, radius, step, 1, (float*)ctx->xbuf.ptr,
+                                    (int*)ctx->flags.ptr));
+            F2_TRY(f2_launch_cnn(ctx, cnn, (const float*)ctx->xbuf.ptr, m, (float*)ctx->work.ptr,
+                                 d_scores ? d_scores + 2 * (done + s) : nullptr, d_labels ? d_labels + done + s : nullptr));
+        }
+        done += nb;
+    }
+    if (mem_space == F2_MEM_HOST) {
+        if (scores_or_null)
+            F2_HIP(ctx, hipMemcpyAsync(scores_or_null, d_scores, sizeof(float) * 2 * (size_t)nb_total, hipMemcpyDeviceToHost, ctx->stream));
+        if (labels_or_null)
+            F2_HIP(ctx, hipMemcpyAsync(labels_or_null, d_labels, (size_t)nb_total, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    int flag = 0;
+    F2_TRY(read_flag(ctx, &flag));
+    F2_CHECK(ctx, !flag, F2_ERR_NONPOSITIVE, "values must all be positive (normalizeInput)");
+    return F2_OK;
+}
+
 }  // extern "C"

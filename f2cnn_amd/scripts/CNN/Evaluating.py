@@ -71,6 +71,46 @@ def EvaluateOneWavFile(file, LPF=False, CUTOFF=50, model='last_trained_model', C
 
 
 # ---- batch / noise evaluation (reference scripts/CNN/Evaluating.py:138-221) -------------
+def EvaluateWavArrays(wavArrays, framerate, model='last_trained_model', LPF=False, CUTOFF=100,
+                      FILTERBANK_COEFFICIENTS=None, ctx=None):
+    """EvaluateOneWavArray for a list of utterances of one sample type in one device pass (f2_eval_batch): the
+    filterbank and envelope kernels see the whole batch, windows and CNN run utterance by utterance.
+    Returns a list of (scores (nb,2) float32, labels (nb,) uint8)."""
+    ctx = ctx or _lib.default_context()
+    cfg = F2Config()
+    if FILTERBANK_COEFFICIENTS is None:
+        FILTERBANK_COEFFICIENTS = filters.make_erb_filters(framerate, filters.centre_freqs(framerate, cfg.nchannels,
+                                                                                           cfg.low_freq))
+    coefs = numpy.ascontiguousarray(FILTERBANK_COEFFICIENTS, dtype=numpy.float64)
+    Cn = coefs.shape[0]
+    if not isinstance(model, F2CNNModel):
+        model = load_model(model)
+    if not len(wavArrays):
+        return []
+    waves, dts = zip(*[filters._wave_args(w) for w in wavArrays])
+    if len(set(dts)) != 1:
+        raise ValueError("the utterances of one batch must share a sample type (int16 or float64)")
+    offsets = numpy.zeros(len(waves) + 1, numpy.int64)
+    offsets[1:] = numpy.cumsum([w.shape[0] for w in waves])
+    flat = numpy.concatenate(waves)
+    STEP = int(framerate * cfg.sampling_period * (1 / 1000000.))
+    nbs = [max(int(w.shape[0] - cfg.dots_per_input * STEP), 0) for w in waves]
+    scores = numpy.empty((sum(nbs), 2), numpy.float32)
+    labels = numpy.empty(sum(nbs), numpy.uint8)
+    try:
+        ctx.eval_batch(model.handle(ctx), flat, dts[0], offsets, coefs, len(waves), Cn, bool(LPF), CUTOFF if LPF else 0.0,
+                       FFT_PRECISION, cfg.radius, STEP, scores, labels, _lib.MEM_HOST)
+    except _lib.F2Error as e:
+        if e.code == _lib.F2_ERR_NONPOSITIVE:
+            raise ValueError("values must all be positive")
+        raise
+    out, pos = [], 0
+    for nb in nbs:
+        out.append((scores[pos:pos + nb], labels[pos:pos + nb]))
+        pos += nb
+    return out
+
+
 def EvaluateRandom(count=None, LPF=False, CUTOFF=50, model='last_trained_model'):
     """`cnn evalrand`: evaluate the WAV files under resources/f2cnn/*/ in random order (all of them, or `count`
     drawn with replacement like numpy.random.choice in the reference). The filterbank is designed once and the model
@@ -94,10 +134,25 @@ def EvaluateRandom(count=None, LPF=False, CUTOFF=50, model='last_trained_model')
     elif count > 1:
         wavFiles = list(numpy.random.choice(wavFiles, count))
     results = {}
-    for file in wavFiles:
-        results[file] = EvaluateOneWavFile(file, LPF=LPF, CUTOFF=CUTOFF, model=model,
-                                           CENTER_FREQUENCIES=CENTER_FREQUENCIES,
-                                           FILTERBANK_COEFFICIENTS=FILTERBANK_COEFFICIENTS)
+    BATCH = 16                                    # files per device pass
+    for s0 in range(0, len(wavFiles), BATCH):
+        group = wavFiles[s0:s0 + BATCH]
+        loaded = [GetArrayFromWAV(file) for file in group]
+        rates = {fr for fr, _ in loaded}
+        if len(rates) == 1 and len({numpy.asarray(w).dtype for _, w in loaded}) == 1:
+            outs = EvaluateWavArrays([w for _, w in loaded], loaded[0][0], model=model, LPF=LPF, CUTOFF=CUTOFF,
+                                     FILTERBANK_COEFFICIENTS=FILTERBANK_COEFFICIENTS)
+        else:                                     # mixed files: one at a time
+            outs = [EvaluateOneWavArray(w, fr, file, model=model, LPF=LPF, CUTOFF=CUTOFF,
+                                        FILTERBANK_COEFFICIENTS=FILTERBANK_COEFFICIENTS if fr == cfg.framerate else None)
+                    for file, (fr, w) in zip(group, loaded)]
+        for file, (scores, labels) in zip(group, outs):
+            out = os.path.splitext(file)[0] + '.F2CNN.npz'
+            numpy.savez(out, scores=scores, labels=labels)
+            rising = int(labels.sum())
+            print("\t\t{}\tdone ! {} windows: {} rising, {} falling -> {}".format(file, len(labels), rising,
+                                                                                  len(labels) - rising, out))
+            results[file] = (scores, labels)
     print("Evaluating network on all files.")
     print('              Total time:', time.time() - TotalTime)
     print('')

@@ -146,6 +146,16 @@ int f2_eval_utterance(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave
                       int radius, int step, double* env_or_null, float* scores_or_null,
                       uint8_t* labels_or_null, int64_t* n_windows_out, int mem_space);
 
+/* The same pipeline for a ragged batch of utterances (scripts/CNN/Evaluating.py:138-177 EvaluateRandom evaluates a
+ * list of files with one model): filterbank and envelope run once for the whole batch - a single utterance only
+ * fills two wavefronts of the filterbank kernel - then windows + CNN utterance by utterance. Utterance b has
+ * nb_b = max(0, n_b - (2*radius+1)*step) windows; scores / labels are the concatenation over b in batch order
+ * (sum nb_b rows), both optional, in `mem_space`.
+ */
+int f2_eval_batch(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave_dtype, const int64_t* offsets,
+                  const double* coefs, int B, int C, int lpf, double cutoff_hz, int fft_precision, int radius,
+                  int step, float* scores_or_null, uint8_t* labels_or_null, int mem_space);
+
 #ifdef __cplusplus
 }
 #endif
