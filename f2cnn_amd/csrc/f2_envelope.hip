@@ -2,34 +2,36 @@
 // (reference: scripts/processing/EnvelopeExtraction.py:20-67 paddedHilbert / lowPassFilter /
 // ExtractEnvelopeFromMatrix).
 //
-// One 256-thread workgroup owns one (utterance, channel) row of n samples, zero-padded to
-// M = 2^ceil(log2 n) exactly as the reference does, and keeps the whole transform on chip:
+// One workgroup (256, 512 or 1024 threads: 16 points per thread for the benchmark sizes) owns one (utterance,
+// channel) row of n samples, zero-padded to M = 2^ceil(log2 n) exactly as the reference does, and keeps the whole
+// transform on chip:
 //
-//   1. the real row is read as H = M/2 complex points  z[m] = x[2m] + i x[2m+1]  (16-byte loads, coalesced)
-//      straight into the registers of the first FFT pass; for float transforms the thread keeps its x
-//      values for step 5
-//   2. Z = FFT_H(z): Stockham passes with a symmetric radix plan (a,b,a), e.g. 16-32-16 for H = 8192; data
-//      moves registers -> LDS -> registers -> LDS -> ..., every pass holds its inputs in registers across
-//      the barrier so the transform is in place; inter-pass twiddles come from per-pass tables laid out
-//      [k][butterfly / stride], i.e. coalesced (first pass) or near-uniform (later passes) loads
+//   1. the real row is read as H = M/2 complex points  z[m] = x[2m] + i x[2m+1]  (16-byte loads of float64 rows, or
+//      8-byte loads of the filterbank kernel's float32 hand-off) straight into the registers of the first FFT pass;
+//      float transforms keep their x values in registers for step 5
+//   2. Z = FFT_H(z): Stockham passes with a symmetric radix plan (first radix = last radix; 16-8-4-16 for H = 8192,
+//      f2_fft_lds.h); data moves registers -> LDS -> registers -> ..., every pass holds its inputs in registers across
+//      the barrier so the transform is in place. Twiddles of passes >= 1 are copied to LDS once per workgroup; a
+//      radix-16 first pass derives its 15 per-butterfly twiddles from two loaded ones
 //   3. the Hilbert transform h = H[x] is real, so its packed spectrum follows from Z by one pass over the
 //      pairs (k, H-k):  W[k] = i sin(t_k) Z[k] + cos(t_k) conj(Z[H-k]),  t_k = 2 pi k / M,  W[0] = 0
 //      (derivation in DESIGN.md); scipy.signal.hilbert's analytic signal is x + i h
 //   4. w = IFFT_H(W), run as conj(FFT(conj W)) (only squares of w are used); because first and last radix
 //      are equal, the last pass leaves in each thread exactly the points it loaded in step 1:
 //      h[2m] = Re w[m], h[2m+1] = Im w[m]
-//   5. env[n] = sqrt(x[n]^2 + h[n]^2) from registers; without low-pass it is stored at once (16-byte
-//      stores). With low-pass  y[n] = b0 (env[n] + env[n-1]) - a1 y[n-1]  runs in float64, time-parallel:
-//      each thread owns a contiguous chunk, runs it from zero state, the chunk-end values are combined by
-//      a multiplicative scan ((-a1)^L per chunk) and the chunk is re-run from its true initial state. The
-//      envelope sits TRANSPOSED in LDS (sample t*L+j at j*257+t) so the chunk sweeps and the coalesced
-//      copy-out are bank-conflict free.
+//   5. env[n] = sqrt(x[n]^2 + h[n]^2) from registers; without low-pass it is stored at once (16-byte stores). With
+//      low-pass, y[n] = b0 (env[n] + env[n-1]) - a1 y[n-1] runs time-parallel in the register layout the FFT left
+//      (lowpass_pairs_store, f2_envelope_core.h: pair -> DPP wave scan -> wave totals -> block chain) and the
+//      outputs leave as 16-byte stores; rows whose first pass does not give every thread whole butterflies (small H)
+//      go through LDS instead: contiguous chunk per thread, zero-state run, multiplicative scan of the chunk ends,
+//      second run, with the envelope TRANSPOSED in LDS (sample t*L+j at j*(NT+1)+t) so sweeps and copy-out are
+//      conflict free.
 //
 // Two real FFTs of length M cost two complex FFTs of length M/2 on 8-byte (f32) points: 64 KiB (+pad) of
 // LDS for the 1 s / 16 kHz row of the benchmark, two workgroups per CU.
-// Bound: HBM, 16 bytes per sample-channel (8 read + 8 written).
+// Bound: HBM, 12-16 bytes per sample-channel (4 or 8 read + 8 written). Rows that do not fit in LDS: f2_envelope_split.hip
+// (four-step transform), f2_envelope_large.hip (global-memory passes).
 #include <cmath>
-
 #include <cstdlib>
 
 #include "f2_fft_lds.h"

@@ -2,16 +2,18 @@
 //
 // Work split: ONE WAVEFRONT = 64 channels of one utterance; lane = channel. The four cascaded
 // second-order sections of a channel (shared poles B1,B2; zeros A11..A14) are advanced sample by
-// sample with all eight float64 state words in registers (transposed direct form II, the recurrence
-// scipy.signal.lfilter evaluates). The input sample is the same for all 64 lanes, so a block of TB
-// samples is staged once in LDS and read back as a broadcast.
+// sample with all eight float64 state words in registers: direct form II with three FMAs per section
+// when the numerators have no z^-2 term (always, for make_erb_filters), else the transposed direct
+// form II recurrence scipy.signal.lfilter evaluates. The input sample is the same for all 64 lanes, so a
+// block of TB samples is staged once in LDS (fetched one block ahead) and read back as a broadcast.
 //
 // The (C,N) C-order output would make every lane store to its own row (stride N*8 bytes). Instead a
 // TB-sample block of results is written to an LDS tile [64 lanes][TB+1] (pad 1 double: conflict-free
 // ds_write_b64 column writes) and then streamed out row by row, so every global store instruction
 // covers 64/TB full row segments of TB*8 contiguous bytes.
 //
-// Bound: HBM writes, 8*C*N bytes per utterance (+2*N read). Arithmetic: 17 f64 ops per sample-channel.
+// Bound: the float64 FMA pipe (13 ops per sample-channel; 17 in the general form); HBM traffic is 8*C*N bytes
+// written per utterance (4*C*N as the float32 hand-off to K2) + 2*N read.
 #include "f2_internal.h"
 
 namespace {
