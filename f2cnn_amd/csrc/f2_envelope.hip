@@ -398,11 +398,10 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     if (lane == 0) yprev = carry;
     {
         // value entering sub-chunk q: chunk-level zero-state part + (-a1)^(q*LS) * yprev
-        double cin = yprev, gq = 1.0;
+        double gq = 1.0;
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const F cq = (F)(q == 0 ? yprev : fma(gq, yprev, ysub[q - 1]));
-            (void)cin;
 #pragma unroll
             for (int j = 0; j < LS; ++j) rl[(q * LS + j) * TP + tid] = cq * qpow[j] + yzs[q * LS + j];
             gq *= gs;
