@@ -5,15 +5,18 @@ EnvelopeExtraction.py:145-149); here one process drives one GPU, so the reads of
 writes of the previous one run on threads (NumPy file I/O releases the GIL) while the GPU works on the current
 batch. Results are written by the caller's `save` exactly as the reference names and formats them.
 """
+import os
 from concurrent.futures import ThreadPoolExecutor
 
 
-def run_batches(items, load, compute, save, batch=32, readers=4, writers=4, max_pending_writes=64):
+def run_batches(items, load, compute, save, batch=32, readers=4, writers=None, max_pending_writes=64):
     """items -> load(item) [threads] -> compute(list of (item, loaded)) -> iterable of (item, result)
     -> save(item, result) [threads]. Order of `compute` calls follows `items`; returns the number of items saved."""
     items = list(items)
     if not items:
         return 0
+    if writers is None:      # the .npy writes (16.4 MB per audio-second and stage) are the slowest stage
+        writers = max(4, min(8, (os.cpu_count() or 8) // 2))
     done = 0
     with ThreadPoolExecutor(readers) as rpool, ThreadPoolExecutor(writers) as wpool:
         def submit_loads(chunk):
