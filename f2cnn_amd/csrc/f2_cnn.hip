@@ -230,6 +230,149 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     }
 }
 
+// ---- conv3 ('same') + conv4 ('valid') + 2x2 max-pool in one kernel, for networks whose pooled conv2 output has four
+// rows (the 11 x C windows of the reference): conv3's output never leaves the CU. One 4-wave workgroup = one window x
+// one tile of 30 conv4 output columns (15 pooled). Phase 1: wave w computes conv3 row w, 32 columns x 64 channels
+// (two N tiles) from a 6 x 34 x 32 patch of the pooled conv2 tensor, writes bias + ReLU into a 4 x 34 x 64 LDS patch.
+// Phase 2: wave w computes conv4 row w & 1, N tile w >> 1 from that patch; the rows meet through LDS for the pool.
+constexpr int T34 = 30;   // conv4 output columns per tile (32 conv3 columns)
+__global__ __launch_bounds__(256) void k_conv34_mfma(const float* __restrict__ in, const float* __restrict__ w3,
+                                                     const float* __restrict__ b3, const float* __restrict__ w4,
+                                                     const float* __restrict__ b4, float* __restrict__ out, int Win,
+                                                     int xtiles, int64_t nwin) {
+    constexpr int PSA = C2 + 4, PSB = C3 + 4;                 // pixel pitches of the two patches (floats)
+    constexpr int NA = 6 * PW * PSA, NB = 4 * PW * PSB;
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    float* pA = lds_all;                                      // [6][34][36]: pooled conv2 rows -1..4, cols c0-1..c0+32
+    float* pB = lds_all + NA;                                 // [4][34][68]: conv3 rows 0..3, cols c0..c0+33 (32, 33 = 0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t win = blockIdx.x / xtiles;
+    const int xt = (int)(blockIdx.x - win * xtiles);
+    const int c0 = T34 * xt;
+    const int Wo4 = Win - 2, Wp = Wo4 / 2;                   // conv4 output / pooled width
+    if (win >= nwin) return;
+
+    const float* img = in + win * (int64_t)4 * Win * C2;
+    for (int e = tid; e < 6 * PW * (C2 / 4); e += 256) {
+        const int r = e / (PW * (C2 / 4));
+        const int rem = e - r * (PW * (C2 / 4));
+        const int p = rem / (C2 / 4), c4 = rem - p * (C2 / 4);
+        const int yi = r - 1, xi = c0 - 1 + p;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yi >= 0 && yi < 4 && xi >= 0 && xi < Win)
+            v = *reinterpret_cast<const float4*>(img + ((int64_t)yi * Win + xi) * C2 + c4 * 4);
+        *reinterpret_cast<float4*>(pA + (r * PW + p) * PSA + c4 * 4) = v;
+    }
+    for (int e = tid; e < 4 * 2 * PSB; e += 256) {            // the two columns conv4's discarded outputs touch
+        const int r = e / (2 * PSB), rem = e - r * (2 * PSB);
+        pB[(r * PW + 32) * PSB + rem] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- phase 1: conv3, row = wave ----
+    {
+        constexpr int HALF = C2 / 2, QN = HALF / 4, NIT = 9 * QN;
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
+        const float* pa0 = pA + (wave * PW + i) * PSA + h * HALF;
+        const float4* wq = reinterpret_cast<const float4*>(w3) + (int64_t)h * QN * C3 + i;
+        float4 av[2], bq[2][2];
+        auto fetch = [&](int it, int buf) {
+            const int tap = it / QN, q = it - tap * QN;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            av[buf] = *reinterpret_cast<const float4*>(pa0 + (dy * PW + dx) * PSA + 4 * q);
+            const float4* pb = wq + (int64_t)tap * 2 * QN * C3 + (int64_t)q * C3;
+            bq[buf][0] = pb[0];
+            bq[buf][1] = pb[32];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cur = it & 1;
+            if (it + 1 < NIT) fetch(it + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float a[4] = {av[cur].x, av[cur].y, av[cur].z, av[cur].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float4 bb = bq[cur][nt];
+                    const float bv = r == 0 ? bb.x : r == 1 ? bb.y : r == 2 ? bb.z : bb.w;
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], bv, acc[nt], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = nt * 32 + i;
+            const float bv = b3[co];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int px = (q & 3) + 8 * (q >> 2) + 4 * h;
+                pB[(wave * PW + px) * PSB + co] = fmaxf(acc[nt][q] + bv, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: conv4, row = wave & 1, N tile = wave >> 1 ----
+    const int r4 = wave & 1, nt4 = wave >> 1;
+    f32x16 acc4;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc4[q] = 0.f;
+    {
+        constexpr int HALF = C3 / 2, QN = HALF / 4, NIT = 9 * QN;
+        const float* pa0 = pB + (r4 * PW + i) * PSB + h * HALF;
+        const float4* wq = reinterpret_cast<const float4*>(w4) + (int64_t)h * QN * C4 + nt4 * 32 + i;
+        float4 av[2], bq[2];
+        auto fetch = [&](int it, int buf) {
+            const int tap = it / QN, q = it - tap * QN;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            av[buf] = *reinterpret_cast<const float4*>(pa0 + (dy * PW + dx) * PSB + 4 * q);
+            bq[buf] = wq[(int64_t)tap * 2 * QN * C4 + (int64_t)q * C4];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cur = it & 1;
+            if (it + 1 < NIT) fetch(it + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float a[4] = {av[cur].x, av[cur].y, av[cur].z, av[cur].w};
+            const float b[4] = {bq[cur].x, bq[cur].y, bq[cur].z, bq[cur].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc4, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // 2x2 pool: the horizontal pair sits in one lane; row 1 hands its eight pair maxima to row 0 through LDS (pA is free)
+    float hm[8];
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) hm[q / 2] = fmaxf(acc4[q], acc4[q + 1]);
+    float* xch = pA + nt4 * (8 * 64);
+    if (r4 == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xch[k * 64 + lane] = hm[k];
+    }
+    __syncthreads();
+    if (r4 == 0) {
+        const int co = nt4 * 32 + i;
+        const float bv = b4[co];
+        float* o = out + win * (int64_t)Wp * C4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = 2 * k;
+            const int xl = (q & 3) + 8 * (q >> 2) + 4 * h;      // even conv4 column inside the tile
+            const int pxp = (c0 + xl) >> 1;
+            const float m = fmaxf(hm[k], xch[k * 64 + lane]);
+            if (xl < T34 && pxp < Wp) o[(int64_t)pxp * C4 + co] = fmaxf(m + bv, 0.f);
+        }
+    }
+}
+
 // ---- dense1: (n, K) x (K, 516) on the same MFMA ----
 // One 6-wave workgroup = 64 windows (two M tiles) x 6 of the 17 output tiles (blockIdx.y picks the group, one output
 // tile per wave, every weight load feeds both M tiles). K is walked in
@@ -374,8 +517,21 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
     // conv1 is evaluated inside conv2's patch staging
     F2_TRY((launch_conv<C1, C2, false, true, 4, 1, true>(ctx, d_x, cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n, cnn->t(0), cnn->t(1))));
-    F2_TRY((launch_conv<C2, C3, true, false, 8, 2>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
-    F2_TRY((launch_conv<C3, C4, false, true, 4, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
+    if (d.Hp1 == 4) {
+        // four pooled rows (the reference's 11-row windows): conv3 + conv4 + pool in one kernel, conv3's output stays in LDS
+        const int xtiles = (2 * d.Wp2 + T34 - 1) / T34;
+        constexpr size_t lds34 = sizeof(float) * (6 * PW * (C2 + 4) + 4 * PW * (C3 + 4));
+        static_assert(lds34 <= 80 * 1024, "two workgroups per CU");
+        F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv34_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds34));
+        const int64_t blocks = n * xtiles;
+        F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
+        hipLaunchKernelGGL(k_conv34_mfma, dim3((unsigned)blocks), dim3(256), lds34, ctx->stream, a2, cnn->t(4), cnn->t(5),
+                           cnn->t(6), cnn->t(7), a4, d.Wp1, xtiles, n);
+        F2_HIP(ctx, hipGetLastError());
+    } else {
+        F2_TRY((launch_conv<C2, C3, true, false, 8, 2>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
+        F2_TRY((launch_conv<C3, C4, false, true, 4, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
+    }
     {
         hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES), dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8),
                            cnn->t(9), a5, d.flat, n);

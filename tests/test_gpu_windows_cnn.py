@@ -68,7 +68,7 @@ def test_eval_windows_normalised():
     assert out.min() == 0.0 and out.max() == 1.0
 
 
-@pytest.mark.parametrize("rows,channels,n", [(11, 128, 257), (11, 64, 40), (13, 40, 33)])
+@pytest.mark.parametrize("rows,channels,n", [(11, 128, 257), (11, 64, 40), (13, 40, 33), (10, 100, 19), (11, 190, 9)])
 def test_cnn_forward_vs_oracle(rows, channels, n):
     m = F2CNNModel.glorot(7, rows, channels, zero_bias=False)
     x = np.random.default_rng(3).random((n, rows, channels)).astype(np.float32)
