@@ -60,7 +60,7 @@ int f2_prof_end(f2_ctx* ctx, int kernel_id) {
 
 extern "C" {
 
-int f2_version(void) { return 100; }
+int f2_version(void) { return 101; }   // 101: f2_eval_batch
 
 int f2_device_count(int* count) {
     if (!count) return f2_fail(nullptr, F2_ERR_INVALID, "count is NULL");

@@ -48,7 +48,7 @@ enum { F2_WAVE_I16 = 0, F2_WAVE_F64 = 1 };
 enum { F2_FFT_F32 = 0, F2_FFT_F64 = 1 };
 
 /* ---- library / context -------------------------------------------------------------------- */
-int f2_version(void);
+int f2_version(void);   /* 100 * major + minor; 101 added f2_eval_batch */
 int f2_device_count(int* count);
 int f2_ctx_create(int device, f2_ctx** ctx);
 int f2_ctx_destroy(f2_ctx* ctx);
