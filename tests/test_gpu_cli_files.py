@@ -137,6 +137,12 @@ def test_batched_eval_matches_one_at_a_time(tmp_path, monkeypatch, capsys):
         np.testing.assert_allclose(scores, s1, atol=2e-5)
         decided = np.abs(s1[:, 1] - s1[:, 0]) > 1e-4
         np.testing.assert_array_equal(labels[decided], l1[decided])
+    # with the low-pass, float64 waves (the evalnoise input type)
+    wf = [w.astype(np.float64) * 0.5 for w in waves[:3]]
+    outs = Evaluating.EvaluateWavArrays(wf, 16000, model=m, LPF=True, CUTOFF=50)
+    for w, (scores, labels) in zip(wf, outs):
+        s1, l1 = Evaluating.EvaluateOneWavArray(w, 16000, model=m, LPF=True, CUTOFF=50)
+        np.testing.assert_allclose(scores, s1, atol=2e-5)
     with pytest.raises(ValueError, match="sample type"):
         Evaluating.EvaluateWavArrays([waves[0], waves[1].astype(np.float64)], 16000, model=m)
     capsys.readouterr()
