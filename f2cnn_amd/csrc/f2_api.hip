@@ -139,6 +139,8 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     for (f2_scratch& s : ctx->tw_split)
         if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->work3.ptr) (void)hipFree(ctx->work3.ptr);
+    if (ctx->handoff.ptr) (void)hipFree(ctx->handoff.ptr);
+    if (ctx->handoff_off.ptr) (void)hipFree(ctx->handoff_off.ptr);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -325,6 +327,34 @@ int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C) {
     return F2_OK;
 }
 
+int f2_plan_handoff(f2_ctx* ctx, const int64_t* h_offsets, int B, int C, int precision, bool want_gfb, f2_handoff* plan) {
+    *plan = f2_handoff();
+    if (want_gfb || precision != F2_FFT_F32) return F2_OK;
+    constexpr size_t SCRATCH_LIMIT = size_t(24) << 30;
+    std::vector<int64_t> off((size_t)B, -1);
+    int64_t floats = 0;
+    bool any_long = false;
+    for (int b = 0; b < B; ++b) {
+        const int64_t n = h_offsets[b + 1] - h_offsets[b];
+        if (n <= (int64_t(2) << 14)) continue;                          // LDS-resident kernels: in the row's own slot
+        const int log2h = f2_log2_ceil(n) - 1;
+        if (!f2_envelope_split_supports(log2h, precision)) return F2_OK;   // a row for the general path: float64 for all
+        off[(size_t)b] = floats;
+        floats += (int64_t)C * n;
+        any_long = true;
+    }
+    if ((size_t)floats * sizeof(float) > SCRATCH_LIMIT) return F2_OK;
+    plan->f32 = true;
+    if (!any_long) return F2_OK;
+    F2_TRY(f2_reserve(ctx, ctx->handoff, sizeof(float) * (size_t)floats));
+    F2_TRY(f2_reserve(ctx, ctx->handoff_off, sizeof(int64_t) * (size_t)B));
+    F2_HIP(ctx, hipMemcpyAsync(ctx->handoff_off.ptr, off.data(), sizeof(int64_t) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `off` is a local
+    plan->d_x32 = (float*)ctx->handoff.ptr;
+    plan->d_x32_off = (const int64_t*)ctx->handoff_off.ptr;
+    return F2_OK;
+}
+
 static size_t wave_elem(int wave_dtype) { return wave_dtype == F2_WAVE_I16 ? 2 : 8; }
 
 extern "C" {
@@ -420,12 +450,13 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
     // When the float64 filterbank output is not wanted and the envelope runs its float32 FFT, the filterbank
     // hands its rows over as float32 inside the ENV buffer itself (half the bytes written and read back;
     // the envelope kernel converts to float32 before its FFT anyway, so the result is bit-identical).
-    const bool f32_handoff = !d_gfb && f2_envelope_accepts_f32(offsets, B, fft_precision);
+    f2_handoff handoff;
+    F2_TRY(f2_plan_handoff(ctx, offsets, B, C, fft_precision, d_gfb != nullptr, &handoff));
     double* k1_out = d_gfb ? d_gfb : d_env;
     F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
-                                (const double*)ctx->coefs.ptr, B, C, k1_out, f32_handoff));
+                                (const double*)ctx->coefs.ptr, B, C, k1_out, &handoff));
     F2_TRY(f2_launch_envelope(ctx, k1_out, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz,
-                              fft_precision, d_env, f32_handoff));
+                              fft_precision, d_env, &handoff));
     if (mem_space == F2_MEM_HOST) {
         F2_HIP(ctx, hipMemcpyAsync(env, d_env, bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (gfb_or_null) F2_HIP(ctx, hipMemcpyAsync(gfb_or_null, d_gfb, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -447,17 +447,10 @@ constexpr int MAX_LOG2H_F64 = 13;  // rows up to 16384 samples
 
 }  // namespace
 
-bool f2_envelope_accepts_f32(const int64_t* h_offsets, int B, int precision) {
-    if (precision != F2_FFT_F32) return false;
-    for (int b = 0; b < B; ++b)
-        if (h_offsets[b + 1] - h_offsets[b] > (int64_t(2) << 14)) return false;   // kernels that keep x in registers (LOG2H <= 14)
-    return true;
-}
-
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
-                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, bool f32_in) {
-    F2_CHECK(ctx, !f32_in || f2_envelope_accepts_f32(h_offsets, B, precision), F2_ERR_INVALID,
-             "float32 hand-off needs the float FFT and rows of at most 32768 samples");
+                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, const f2_handoff* handoff) {
+    const bool f32_in = handoff && handoff->f32;
+    F2_CHECK(ctx, !f32_in || precision == F2_FFT_F32, F2_ERR_INVALID, "float32 hand-off needs the float FFT");
     EnvParams P;
     P.f32_in = f32_in ? 1 : 0;
     P.stamps = nullptr;
@@ -488,7 +481,6 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         const int maxl = precision == F2_FFT_F32 ? MAX_LOG2H_F32 : MAX_LOG2H_F64;
         if (log2h > maxl && f2_envelope_split_supports(log2h, precision)) {
             // longer than the LDS-resident transform: four-step transform, all utterances of a size together
-            F2_CHECK(ctx, !f32_in, F2_ERR_INVALID, "float32 hand-off is not available for long rows");
             split_groups[log2h].push_back(b);
             ++n_large;
             continue;
@@ -508,7 +500,8 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
     for (int log2h = 0; log2h < 32; ++log2h)
         if (!split_groups[log2h].empty())
             F2_TRY(f2_launch_envelope_split(ctx, d_gfb, d_env, d_offsets, split_groups[log2h].data(),
-                                            (int)split_groups[log2h].size(), log2h, C, P.lpf, P.b0, P.a1));
+                                            (int)split_groups[log2h].size(), log2h, C, P.lpf, P.b0, P.a1,
+                                            f32_in ? handoff->d_x32 : nullptr, f32_in ? handoff->d_x32_off : nullptr));
     size_t list_elems = 0;
     int ngroups = 0;
     for (auto& g : groups)

@@ -20,7 +20,9 @@
 //       the filter state carried from segment to segment (coalesced 16-byte loads and stores)
 //
 // A and C share one scratch array of H complex floats per row; utterances are processed in groups that keep it
-// under SCRATCH_CAP bytes. Algorithmic bytes per sample-channel: 8+4 (KA) + 4+4 (KB) + 4+8+8 (KC) + 8+8 (KL).
+// under SCRATCH_CAP bytes. Algorithmic bytes per sample-channel: 8+4 (KA) + 4+4 (KB) + 4+8+8 (KC) + 8+8 (KL); the reads
+// of x drop to 4 bytes when the filterbank handed its rows over as float32 (x32: compact rows in a scratch buffer - not
+// in the output slots, where KC's float64 stores would overwrite samples other workgroups have not read yet).
 #include <algorithm>
 
 #include "f2_fft_lds.h"
@@ -47,10 +49,13 @@ struct SplitParams {
     const cpx<float>* t1;      // [H1]: (cos, sin)(pi k1 / H)
     const cpx<float>* t2;      // [H2]: (cos, sin)(pi k2 / H2)
     const cpx<float>* tw12;    // tables of the 4096-point transform (ensure_twiddles<float>(12))
+    const float* x32;          // float32 hand-off of the filterbank: compact (C, n) rows at x32 + x32_off[b], or NULL
+    const int64_t* x32_off;
 };
 
 struct Row {
-    const double* x;
+    const double* x;     // float64 input row (when xf is NULL)
+    const float* xf;     // float32 input row, or NULL
     double* y;
     int n;
 };
@@ -60,7 +65,15 @@ __device__ __forceinline__ Row row_of(const SplitParams& P, int r) {
     const int64_t off = P.offsets[b];
     const int n = (int)(P.offsets[b + 1] - off);
     const size_t row = (size_t)P.C * (size_t)off + (size_t)c * (size_t)n;
-    return {P.gfb + row, P.env + row, n};
+    const float* xf = P.x32 ? P.x32 + P.x32_off[b] + (size_t)c * (size_t)n : nullptr;
+    return {P.gfb + row, xf, P.env + row, n};
+}
+// samples i0, i0 + 1 of the row as floats (0 beyond the end); clamped addresses, no divergent loads
+__device__ __forceinline__ cpx<float> load_pair(const Row& rw, int i0) {
+    const int a = min(i0, rw.n - 1), b = min(i0 + 1, rw.n - 1);
+    const float va = rw.xf ? rw.xf[a] : (float)rw.x[a];
+    const float vb = rw.xf ? rw.xf[b] : (float)rw.x[b];
+    return {i0 < rw.n ? va : 0.f, i0 + 1 < rw.n ? vb : 0.f};
 }
 
 template <int H1>
@@ -70,9 +83,7 @@ __global__ __launch_bounds__(256) void k_split_first(SplitParams P) {
     cpx<float> v[H1];
 #pragma unroll
     for (int n1 = 0; n1 < H1; ++n1) {
-        const int i0 = 2 * (n2 + H2 * n1);
-        const double a = rw.x[min(i0, rw.n - 1)], b = rw.x[min(i0 + 1, rw.n - 1)];   // clamped: no divergent loads
-        v[n1] = {i0 < rw.n ? (float)a : 0.f, i0 + 1 < rw.n ? (float)b : 0.f};
+        v[n1] = load_pair(rw, 2 * (n2 + H2 * n1));
     }
     dft<H1>(v);   // X[k1] in v[brev<H1>(k1)]
     cpx<float>* A = P.scratch + (size_t)r * (H1 * H2);
@@ -148,25 +159,18 @@ __global__ __launch_bounds__(256) void k_split_last(SplitParams P) {
         v[k1] = k1 == 0 ? c : cmul(c, P.twa[k1 * H2 + m2]);
     }
     dft<H1>(v);   // w~[m2 + H2 m1] in v[brev<H1>(m1)]
-    const bool pairs_ok = ((reinterpret_cast<uintptr_t>(rw.y) | reinterpret_cast<uintptr_t>(rw.x)) & 15) == 0;
+    const bool pairs_ok = (reinterpret_cast<uintptr_t>(rw.y) & 15) == 0;
 #pragma unroll
     for (int m1 = 0; m1 < H1; ++m1) {
         const int i0 = 2 * (m2 + H2 * m1);
         const cpx<float> w = v[brev<H1>(m1)];
+        const cpx<float> xx = load_pair(rw, i0);   // (with float64 rows in place: exactly the samples overwritten below)
+        const double e0 = (double)fsqrt(xx.re * xx.re + w.re * w.re), e1 = (double)fsqrt(xx.im * xx.im + w.im * w.im);
         if (i0 + 1 < rw.n && pairs_ok) {
-            const double2 xx = *reinterpret_cast<const double2*>(rw.x + i0);
-            const float a = (float)xx.x, b = (float)xx.y;
-            *reinterpret_cast<double2*>(rw.y + i0) =
-                make_double2((double)fsqrt(a * a + w.re * w.re), (double)fsqrt(b * b + w.im * w.im));
+            *reinterpret_cast<double2*>(rw.y + i0) = make_double2(e0, e1);
         } else {
-            if (i0 < rw.n) {
-                const float a = (float)rw.x[i0];
-                rw.y[i0] = (double)fsqrt(a * a + w.re * w.re);
-            }
-            if (i0 + 1 < rw.n) {
-                const float b = (float)rw.x[i0 + 1];
-                rw.y[i0 + 1] = (double)fsqrt(b * b + w.im * w.im);
-            }
+            if (i0 < rw.n) rw.y[i0] = e0;
+            if (i0 + 1 < rw.n) rw.y[i0 + 1] = e1;
         }
     }
 }
@@ -257,7 +261,8 @@ bool f2_envelope_split_supports(int log2h, int precision) {
 
 // All utterances `utts` (indices into the batch) have the same transform size 2^log2h complex points.
 int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets, const int* utts,
-                             int nutt, int log2h, int C, int lpf, double b0, double a1) {
+                             int nutt, int log2h, int C, int lpf, double b0, double a1, const float* d_x32,
+                             const int64_t* d_x32_off) {
     if (nutt <= 0) return F2_OK;
     F2_CHECK(ctx, f2_envelope_split_supports(log2h, F2_FFT_F32), F2_ERR_INVALID, "unsupported split size 2^%d", log2h);
     const int H1 = 1 << (log2h - LOG2H2);
@@ -283,6 +288,8 @@ int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, co
     P.t1 = P.twa + H;
     P.t2 = P.t1 + H1;
     P.tw12 = (const cpx<float>*)ctx->tw[0][LOG2H2].ptr;
+    P.x32 = d_x32;
+    P.x32_off = d_x32_off;
     for (int done = 0; done < nutt; done += per_group) {
         const int g = std::min(per_group, nutt - done);
         P.ulist = (const int*)ctx->work3.ptr + done;

@@ -30,7 +30,8 @@ template <typename WaveT, typename OutT, bool A2ZERO>
 __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__ wave,
                                                        const int64_t* __restrict__ offsets,
                                                        const double* __restrict__ coefs, int C,
-                                                       int groups, double* __restrict__ out) {
+                                                       int groups, double* __restrict__ out,
+                                                       float* __restrict__ alt, const int64_t* __restrict__ alt_off) {
     __shared__ OutT tile[64][TB + 1];
     __shared__ double xs[TB];
 
@@ -57,8 +58,17 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
     double z10 = 0, z11 = 0, z20 = 0, z21 = 0, z30 = 0, z31 = 0, z40 = 0, z41 = 0;
 
     const WaveT* w = wave + off;
-    constexpr int ROWMUL = sizeof(double) / sizeof(OutT);   // row pitch in OutT elements = ROWMUL * N
+    // row pitch in OutT elements = ROWMUL * N: float rows sit at the start of their float64 slot, unless this utterance
+    // hands its rows over in the compact scratch layout (alt_off[b] >= 0: (C, N) float rows at alt + alt_off[b])
+    int ROWMUL = sizeof(double) / sizeof(OutT);
     char* obase = reinterpret_cast<char*>(out + (size_t)C * (size_t)off);
+    if (sizeof(OutT) == 4 && alt_off) {
+        const int64_t ao = alt_off[b];
+        if (ao >= 0) {
+            ROWMUL = 1;
+            obase = reinterpret_cast<char*>(alt + ao);
+        }
+    }
     const int srow = lane / TB, scol = lane % TB;
     // byte offsets inside this utterance's block fit 32 bits up to 512 Mi sample-channels
     const bool fits32 = (uint64_t)C * (uint64_t)N * 8u < (uint64_t(1) << 32);
@@ -180,19 +190,23 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
 
 template <typename WaveT, typename OutT>
 void launch_fb(hipStream_t st, dim3 grid, bool a2zero, const void* wave, const int64_t* offsets, const double* coefs, int C,
-               int groups, double* out) {
+               int groups, double* out, float* alt = nullptr, const int64_t* alt_off = nullptr) {
     if (a2zero)
         hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true>), grid, dim3(64), 0, st, (const WaveT*)wave, offsets, coefs, C,
-                           groups, out);
+                           groups, out, alt, alt_off);
     else
         hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, false>), grid, dim3(64), 0, st, (const WaveT*)wave, offsets, coefs,
-                           C, groups, out);
+                           C, groups, out, alt, alt_off);
 }
 
 }  // namespace
 
 int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,
-                         const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb, bool f32_out) {
+                         const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb,
+                         const f2_handoff* handoff) {
+    const bool f32_out = handoff && handoff->f32;
+    float* alt = f32_out ? handoff->d_x32 : nullptr;
+    const int64_t* alt_off = f32_out ? handoff->d_x32_off : nullptr;
     (void)h_offsets;
     const int groups = (C + 63) / 64;
     const dim3 grid((unsigned)(B * groups));
@@ -203,11 +217,11 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
     if (wave_dtype == F2_WAVE_I16 && !f32_out)
         launch_fb<int16_t, double>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
     else if (wave_dtype == F2_WAVE_I16)
-        launch_fb<int16_t, float>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
+        launch_fb<int16_t, float>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off);
     else if (!f32_out)
         launch_fb<double, double>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
     else
-        launch_fb<double, float>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
+        launch_fb<double, float>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_FILTERBANK));
     return F2_OK;

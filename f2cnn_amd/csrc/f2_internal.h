@@ -36,6 +36,7 @@ struct f2_ctx {
     f2_scratch tw_large[2][24];   // same for the global-memory transform of long rows
     f2_scratch tw_split[24];      // tables of the four-step transform (f2_envelope_split.hip), by log2 H
     f2_scratch work3;             // utterance lists of the four-step launches
+    f2_scratch handoff, handoff_off;   // float32 hand-off of long rows (f2_plan_handoff)
     std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
     std::vector<double> coefs_host;     // what ctx->coefs currently holds
     bool prof_on = false;
@@ -90,7 +91,8 @@ int f2_prof_end(f2_ctx* ctx, int kernel_id);
 // rows between the LDS limit and 262144 samples: four-step transform with LDS-resident 4096-point parts
 bool f2_envelope_split_supports(int log2h, int precision);
 int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets, const int* utts,
-                             int nutt, int log2h, int C, int lpf, double b0, double a1);
+                             int nutt, int log2h, int C, int lpf, double b0, double a1, const float* d_x32,
+                             const int64_t* d_x32_off);
 #define F2_MAX_LOG2M_LARGE 22
 int f2_launch_envelope_large(f2_ctx* ctx, const double* d_x, double* d_y, int64_t n, int C, int lpf, double b0,
                              double a1, int precision);
@@ -102,13 +104,22 @@ static inline int f2_log2_ceil(int64_t n) {
 }
 
 // ---- launchers implemented in the kernel translation units (device pointers only) ----
+// How the filterbank hands its rows to the envelope kernels inside one call (decided from the utterance lengths):
+// float64 rows in the output buffer, or float32 - at the start of each row's float64 slot for rows the LDS-resident
+// kernel takes (<= 32768 samples), compact (C, n) float rows in a scratch buffer for the four-step path (whose last
+// pass writes float64 results over the slot while other workgroups still read their inputs).
+struct f2_handoff {
+    bool f32 = false;
+    float* d_x32 = nullptr;                 // scratch of the long rows, or NULL when there are none
+    const int64_t* d_x32_off = nullptr;     // device, per utterance: float offset into d_x32, -1 = in the row's own slot
+};
+int f2_plan_handoff(f2_ctx* ctx, const int64_t* h_offsets, int B, int C, int precision, bool want_gfb, f2_handoff* plan);
 int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,
                          const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb,
-                         bool f32_out = false);
+                         const f2_handoff* handoff = nullptr);
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
-                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, bool f32_in = false);
-// true when every utterance can take the float32 hand-off between K1 and K2 (float FFT, x kept in registers)
-bool f2_envelope_accepts_f32(const int64_t* h_offsets, int B, int precision);
+                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env,
+                       const f2_handoff* handoff = nullptr);
 // d_centers == NULL: window e is centred at first_center + e
 int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const int64_t* d_centers,
                      int64_t first_center, int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag);

@@ -236,11 +236,12 @@ int f2_eval_batch(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave_dty
         F2_HIP(ctx, hipMemcpyAsync(ctx->stage_in.ptr, wave, wb, hipMemcpyHostToDevice, ctx->stream));
         d_wave = ctx->stage_in.ptr;
     }
-    const bool f32_handoff = f2_envelope_accepts_f32(offsets, B, fft_precision);
+    f2_handoff handoff;
+    F2_TRY(f2_plan_handoff(ctx, offsets, B, C, fft_precision, false, &handoff));
     F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
-                                (const double*)ctx->coefs.ptr, B, C, d_env, f32_handoff));
+                                (const double*)ctx->coefs.ptr, B, C, d_env, &handoff));
     F2_TRY(f2_launch_envelope(ctx, d_env, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz, fft_precision,
-                              d_env, f32_handoff));
+                              d_env, &handoff));
     if (nb_total == 0) {
         if (mem_space == F2_MEM_HOST) F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return F2_OK;
