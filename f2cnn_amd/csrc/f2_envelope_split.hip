@@ -16,11 +16,12 @@
 //         w~[m2 + H2 m1] (only its squares are used), env[2m] = sqrt(x[2m]^2 + Re^2), env[2m+1] = sqrt(x[2m+1]^2 + Im^2)
 //       written as float64 (in place over x when the caller transforms in place: a thread reads exactly the x it
 //       overwrites)
-//   KL  optional low-pass, in place, one workgroup per row, 16384-sample segments through lowpass_pairs_store with
-//       the filter state carried from segment to segment (coalesced 16-byte loads and stores)
+//   KL  optional low-pass (KC then leaves the envelope as float pairs in the scratch row instead of writing float64),
+//       one workgroup per row, 16384-sample segments through lowpass_pairs_store with the filter state carried from
+//       segment to segment (coalesced 8-byte loads, 16-byte stores)
 //
 // A and C share one scratch array of H complex floats per row; utterances are processed in groups that keep it
-// under SCRATCH_CAP bytes. Algorithmic bytes per sample-channel: 8+4 (KA) + 4+4 (KB) + 4+8+8 (KC) + 8+8 (KL); the reads
+// under SCRATCH_CAP bytes. Algorithmic bytes per sample-channel: 8+4 (KA) + 4+4 (KB) + 4+8+4 (KC) + 4+8 (KL), KC 4+8+8 without low-pass; the reads
 // of x drop to 4 bytes when the filterbank handed its rows over as float32 (x32: compact rows in a scratch buffer - not
 // in the output slots, where KC's float64 stores would overwrite samples other workgroups have not read yet).
 #include <algorithm>
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256) void k_split_last(SplitParams P) {
     const int r = blockIdx.x, m2 = blockIdx.y * 256 + threadIdx.x;
     const Row rw = row_of(P, r);
     const cpx<float>* Cm = P.scratch + (size_t)r * (H1 * H2);
+    cpx<float>* Ce = P.scratch + (size_t)r * (H1 * H2);
     cpx<float> v[H1];
 #pragma unroll
     for (int k1 = 0; k1 < H1; ++k1) {
@@ -165,7 +167,14 @@ __global__ __launch_bounds__(256) void k_split_last(SplitParams P) {
         const int i0 = 2 * (m2 + H2 * m1);
         const cpx<float> w = v[brev<H1>(m1)];
         const cpx<float> xx = load_pair(rw, i0);   // (with float64 rows in place: exactly the samples overwritten below)
-        const double e0 = (double)fsqrt(xx.re * xx.re + w.re * w.re), e1 = (double)fsqrt(xx.im * xx.im + w.im * w.im);
+        const float f0 = fsqrt(xx.re * xx.re + w.re * w.re), f1 = fsqrt(xx.im * xx.im + w.im * w.im);
+        if (P.lpf) {
+            // the low-pass follows: leave the envelope as float pairs in the scratch row, in time order - position
+            // m2 + H2 m1 is one of the positions this thread has just read, so the row is rewritten in place
+            Ce[m1 * H2 + m2] = {f0, f1};
+            continue;
+        }
+        const double e0 = (double)f0, e1 = (double)f1;
         if (i0 + 1 < rw.n && pairs_ok) {
             *reinterpret_cast<double2*>(rw.y + i0) = make_double2(e0, e1);
         } else {
@@ -175,8 +184,10 @@ __global__ __launch_bounds__(256) void k_split_last(SplitParams P) {
     }
 }
 
-// in-place first-order low-pass of a float64 row, 2*LNT*LNB = 16384 samples per step
+// first-order low-pass of the float envelope pairs k_split_last left in the scratch row -> float64 output row,
+// 2*LNT*LNB = 16384 samples per step
 constexpr int LNT = 512, LNB = 16;
+template <int H1>
 __global__ __launch_bounds__(LNT, 4) void k_split_lowpass(SplitParams P) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[lowpass_lds_bytes<float, LNT, LNB>()];
     __shared__ float e_last;
@@ -185,6 +196,7 @@ __global__ __launch_bounds__(LNT, 4) void k_split_lowpass(SplitParams P) {
     double* y = rw.y;
     const int n = rw.n;
     const bool al16 = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const cpx<float>* __restrict__ e = P.scratch + (size_t)blockIdx.x * (H1 * H2);   // envelope pairs left by k_split_last
     double ycarry = 0.0;
     float ecarry = 0.f;
     for (int base = 0; base < n; base += 2 * LNT * LNB) {
@@ -193,14 +205,9 @@ __global__ __launch_bounds__(LNT, 4) void k_split_lowpass(SplitParams P) {
 #pragma unroll
         for (int jj = 0; jj < LNB; ++jj) {
             const int i0 = 2 * (tid + LNT * jj);
-            if (al16 && i0 + 1 < left) {
-                const double2 e = *reinterpret_cast<const double2*>(y + base + i0);
-                er[jj] = (float)e.x;
-                ei[jj] = (float)e.y;
-            } else {
-                er[jj] = i0 < left ? (float)y[base + i0] : 0.f;
-                ei[jj] = i0 + 1 < left ? (float)y[base + i0 + 1] : 0.f;
-            }
+            const cpx<float> p = e[min((base + i0) >> 1, H1 * H2 - 1)];
+            er[jj] = i0 < left ? p.re : 0.f;
+            ei[jj] = i0 + 1 < left ? p.im : 0.f;
         }
         if (tid == LNT - 1) e_last = ei[LNB - 1];   // e[-1] of the next segment
         __syncthreads();   // every load of this segment precedes every store; smem and e_last are settled
@@ -247,7 +254,7 @@ int launch_group(f2_ctx* ctx, const SplitParams& P, int nutt) {
     hipLaunchKernelGGL(k_split_last<H1>, dim3((unsigned)nrows, H2 / 256), dim3(256), 0, ctx->stream, P);
     F2_HIP(ctx, hipGetLastError());
     if (P.lpf) {
-        hipLaunchKernelGGL(k_split_lowpass, dim3((unsigned)nrows), dim3(LNT), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_split_lowpass<H1>, dim3((unsigned)nrows), dim3(LNT), 0, ctx->stream, P);
         F2_HIP(ctx, hipGetLastError());
     }
     return F2_OK;
