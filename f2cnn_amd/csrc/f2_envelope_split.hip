@@ -124,23 +124,28 @@ __global__ __launch_bounds__(2 * NTH, 4) void k_split_mid(SplitParams P) {
     // Hilbert pair step in registers; all reads of both halves' spectra precede the next transform's LDS writes
     const cpx<float> r1 = P.t1[ka];
     const float sc = 1.0f / (float)(H1 * H2);
-    cpx<float> zk[R0], zm[R0], r2[R0];
+    // (v is dead after the forward transform - its outputs went to LDS - so W~ is formed straight into it, four points at
+    // a time to keep the loads in flight without holding all 48 operands)
 #pragma unroll
-    for (int j = 0; j < R0; ++j) {
-        const int k2 = t + j * NB0;
-        const int km = ka == 0 ? ((H2 - k2) & (H2 - 1)) : H2 - 1 - k2;
-        zk[j] = own[cpad(k2)];
-        zm[j] = partner[cpad(km)];
-        r2[j] = P.t2[k2];
-    }
-    __syncthreads();
+    for (int j0 = 0; j0 < R0; j0 += 4) {
+        cpx<float> zk[4], zm[4], r2[4];
 #pragma unroll
-    for (int j = 0; j < R0; ++j) {
-        const float cs = (r1.re * r2[j].re - r1.im * r2[j].im) * sc;   // cos(t_k) / H
-        const float sn = (r1.im * r2[j].re + r1.re * r2[j].im) * sc;   // sin(t_k) / H
-        const bool dc = ka == 0 && t + j * NB0 == 0;
-        v[j] = {dc ? 0.f : -sn * zk[j].im + cs * zm[j].re, dc ? 0.f : -(sn * zk[j].re - cs * zm[j].im)};
+        for (int q = 0; q < 4; ++q) {
+            const int k2 = t + (j0 + q) * NB0;
+            const int km = ka == 0 ? ((H2 - k2) & (H2 - 1)) : H2 - 1 - k2;
+            zk[q] = own[cpad(k2)];
+            zm[q] = partner[cpad(km)];
+            r2[q] = P.t2[k2];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float cs = (r1.re * r2[q].re - r1.im * r2[q].im) * sc;   // cos(t_k) / H
+            const float sn = (r1.im * r2[q].re + r1.re * r2[q].im) * sc;   // sin(t_k) / H
+            const bool dc = ka == 0 && t + (j0 + q) * NB0 == 0;
+            v[j0 + q] = {dc ? 0.f : -sn * zk[q].im + cs * zm[q].re, dc ? 0.f : -(sn * zk[q].re - cs * zm[q].im)};
+        }
     }
+    __syncthreads();   // all reads of both halves' spectra precede the next transform's LDS writes
     fft_regs_to_regs<float, LOG2H2, PT, NTH, T0R>(own, P.tw12, twl, t, v);   // point t + j*NB0 in v[brev<R0>(j)]
     if (half == 0 || !self) {
 #pragma unroll
