@@ -85,8 +85,9 @@ def erb_filterbank(wave, coefs, ctx=None):
     return out
 
 
-def erb_filterbank_batch(waves, coefs, ctx=None):
-    """List of waveforms (same dtype, any lengths) -> list of (C,N_b) matrices in one launch."""
+def erb_filterbank_batch(waves, coefs, ctx=None, alloc=np.empty):
+    """List of waveforms (same dtype, any lengths) -> list of (C,N_b) matrices in one launch. `alloc(count, dtype=...)`
+    provides the output buffer (the file drivers pass a recycling pool)."""
     ctx = ctx or _lib.default_context()
     coefs = np.ascontiguousarray(coefs, dtype=np.float64)
     if not len(waves):
@@ -98,6 +99,6 @@ def erb_filterbank_batch(waves, coefs, ctx=None):
     offsets[1:] = np.cumsum([a[0].shape[0] for a in args])
     flat = np.concatenate([a[0].astype(dtype, copy=False) for a in args]) if offsets[-1] else np.zeros(0, dtype)
     Cn = coefs.shape[0]
-    out = np.empty(Cn * int(offsets[-1]), dtype=np.float64)
+    out = alloc(Cn * int(offsets[-1]), dtype=np.float64)
     ctx.erb_filterbank_batch(flat, dt, offsets, coefs, len(args), Cn, out, _lib.MEM_HOST)
     return [out[Cn * offsets[b]:Cn * offsets[b + 1]].reshape(Cn, -1) for b in range(len(args))]

@@ -6,7 +6,11 @@ writes of the previous one run on threads (NumPy file I/O releases the GIL) whil
 batch. Results are written by the caller's `save` exactly as the reference names and formats them.
 """
 import os
+import sys
+import threading
 from concurrent.futures import ThreadPoolExecutor
+
+import numpy
 
 
 def run_batches(items, load, compute, save, batch=32, readers=4, writers=None, max_pending_writes=64):
@@ -35,3 +39,40 @@ def run_batches(items, load, compute, save, batch=32, readers=4, writers=None, m
         for w in writes:
             w.result()
     return done
+
+
+class ArrayPool:
+    """Recycles the large host arrays of the file drivers. A fresh numpy.empty of half a gigabyte is page-faulted in
+    by the device-to-host copy that fills it (about 30 ms per 16-file batch, more than the copy and the kernels
+    together); an array whose pages are already mapped is not. An owner array is free again when nothing but the
+    pool refers to it: every view handed out (and every view of a view) holds a reference to its owner."""
+
+    def __init__(self, keep=6):
+        self._owners = []
+        self._lock = threading.Lock()
+        self.keep = keep
+
+    def empty(self, count, dtype=numpy.float64):
+        """Uninitialised 1-D array of `count` elements backed by a pooled buffer."""
+        dtype = numpy.dtype(dtype)
+        nbytes = int(count) * dtype.itemsize
+        with self._lock:
+            best = None
+            for i in range(len(self._owners)):
+                o = self._owners[i]
+                # references: the list, `o`, getrefcount's argument
+                if o.nbytes >= nbytes and sys.getrefcount(o) <= 3 and (best is None or o.nbytes < best.nbytes):
+                    best = o
+                del o
+            if best is None:
+                best = numpy.empty(max(nbytes + nbytes // 8, 1 << 20), numpy.uint8)
+                self._owners.append(best)
+                if len(self._owners) > self.keep:   # drop the smallest buffer nobody uses
+                    idle = [o for o in self._owners if o is not best and sys.getrefcount(o) <= 4]
+                    if idle:
+                        victim = min(idle, key=lambda o: o.nbytes)
+                        self._owners = [o for o in self._owners if o is not victim]
+            return best[:nbytes].view(dtype)
+
+
+host_pool = ArrayPool()

@@ -12,7 +12,7 @@ import time
 import numpy
 
 from ... import _lib
-from ...iopipe import run_batches
+from ...iopipe import host_pool, run_batches
 from ...runtime import shard_for_rank
 
 FFT_PRECISION = _lib.FFT_F64 if os.environ.get("F2CNN_FFT", "f32").lower() in ("f64", "double") else _lib.FFT_F32
@@ -34,17 +34,21 @@ def ExtractEnvelopeFromMatrix(matrix, LPF=False, CUTOFF=100, ctx=None, precision
     return out
 
 
-def ExtractEnvelopesFromMatrices(matrices, LPF=False, CUTOFF=100, ctx=None, precision=None):
-    """Batched form: a list of (C,N_b) matrices with the same C -> list of envelopes, one launch per FFT size."""
+def ExtractEnvelopesFromMatrices(matrices, LPF=False, CUTOFF=100, ctx=None, precision=None, alloc=numpy.empty):
+    """Batched form: a list of (C,N_b) matrices with the same C -> list of envelopes, one launch per FFT size.
+    `alloc(count, dtype=...)` provides the output buffer."""
     ctx = ctx or _lib.default_context()
     if not len(matrices):
         return []
     Cn = matrices[0].shape[0]
     offsets = numpy.zeros(len(matrices) + 1, dtype=numpy.int64)
     offsets[1:] = numpy.cumsum([m.shape[1] for m in matrices])
-    flat = numpy.concatenate([numpy.ascontiguousarray(m, dtype=numpy.float64).ravel() for m in matrices])
-    out = numpy.empty_like(flat)
-    ctx.envelope_batch(flat, offsets, len(matrices), Cn, bool(LPF), CUTOFF if LPF else 0.0,
+    # one host buffer: the matrices are packed into it, the library copies it to the device, transforms in place
+    # there and copies the envelopes back over it
+    out = alloc(Cn * int(offsets[-1]), dtype=numpy.float64)
+    for b, m in enumerate(matrices):
+        out[Cn * offsets[b]:Cn * offsets[b + 1]].reshape(Cn, -1)[...] = m
+    ctx.envelope_batch(out, offsets, len(matrices), Cn, bool(LPF), CUTOFF if LPF else 0.0,
                        FFT_PRECISION if precision is None else precision, out, _lib.MEM_HOST)
     return [out[Cn * offsets[b]:Cn * offsets[b + 1]].reshape(Cn, -1) for b in range(len(matrices))]
 
@@ -98,7 +102,8 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16):
             by_c.setdefault(m.shape[0], []).append(i)
         envs = [None] * len(loaded)
         for idx in by_c.values():
-            for i, e in zip(idx, ExtractEnvelopesFromMatrices([loaded[i][1] for i in idx], LPF, CUTOFF)):
+            for i, e in zip(idx, ExtractEnvelopesFromMatrices([loaded[i][1] for i in idx], LPF, CUTOFF,
+                                                                alloc=host_pool.empty)):
                 envs[i] = e
         return [(loaded[i][0], envs[i]) for i in range(len(loaded))]
 
@@ -146,8 +151,8 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True):
         offsets = numpy.zeros(len(args) + 1, dtype=numpy.int64)
         offsets[1:] = numpy.cumsum([a[0].shape[0] for a in args])
         flat = numpy.concatenate([a[0].astype(dtype, copy=False) for a in args])
-        env = numpy.empty(Cn * int(offsets[-1]), dtype=numpy.float64)
-        gfb = numpy.empty_like(env) if keep_gfb else None
+        env = host_pool.empty(Cn * int(offsets[-1]))
+        gfb = host_pool.empty(Cn * int(offsets[-1])) if keep_gfb else None
         ctx.filterbank_envelope_fused(flat, dt, offsets, coefs, len(args), Cn, bool(LPF), CUTOFF if LPF else 0.0,
                                       FFT_PRECISION, env, gfb, _lib.MEM_HOST)
         for b, (name, _) in enumerate(loaded):

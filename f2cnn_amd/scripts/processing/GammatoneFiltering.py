@@ -12,7 +12,7 @@ import numpy
 
 from ...config import F2Config
 from ...gammatone import filters
-from ...iopipe import run_batches
+from ...iopipe import host_pool, run_batches
 from ...runtime import shard_for_rank
 from ...wavio import read_audio
 
@@ -75,7 +75,7 @@ def FilterAllOrganisedFiles(batch_files=32):
 
     def compute(loaded):
         names = [n for n, _ in loaded]
-        return zip(names, filters.erb_filterbank_batch([w for _, w in loaded], coefs))
+        return zip(names, filters.erb_filterbank_batch([w for _, w in loaded], coefs, alloc=host_pool.empty))
 
     def save(name, m):
         gfb = os.path.splitext(name)[0] + '.GFB'

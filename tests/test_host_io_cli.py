@@ -139,3 +139,24 @@ def test_iopipe_order_and_completeness():
     assert seen == [list(range(s, min(s + 5, 23))) for s in range(0, 23, 5)]
     assert saved == {i: i * 10 + 1 for i in range(23)}
     assert run_batches([], load, compute, save) == 0
+
+
+def test_array_pool_recycles_only_unreferenced_owners():
+    from f2cnn_amd.iopipe import ArrayPool
+    pool = ArrayPool(keep=3)
+    a = pool.empty(1000)
+    owner_a = a.base
+    addr_a = owner_a.ctypes.data
+    del owner_a
+    b = pool.empty(500)
+    assert b.base.ctypes.data != addr_a                    # a is alive: a second owner
+    view = a[10:20].reshape(2, 5)                           # a view of a view keeps the owner busy
+    del a
+    c = pool.empty(800)
+    assert c.base.ctypes.data != addr_a
+    del view
+    d = pool.empty(900, dtype=np.float32)
+    assert d.base.ctypes.data == addr_a and d.dtype == np.float32 and d.shape == (900,)
+    for _ in range(10):                                     # the pool does not grow without bound
+        pool.empty(100)
+    assert len(pool._owners) <= 4
