@@ -17,8 +17,9 @@
 // (A operand, lane = pixel) and one 16-byte load of the re-laid-out weights wt[tap][h][s/4][cout][s%4] (B operand,
 // lane = Cout); both are requested one step ahead of the MFMAs that use them. ReLU, bias and the 2x2 max-pool are
 // applied from the accumulators: the 32x32 accumulator keeps pixel pairs (2t, 2t+1) in one lane, and the second
-// pooled row is the wave's second M-tile, so pooling needs no cross-lane traffic. conv1 has no kernel of its own:
-// conv2's staging evaluates it (FUSE1 below).
+// pooled row is the wave's second M-tile, so pooling needs no cross-lane traffic (k_conv3x3_mfma). The reference's
+// window shape runs two fused kernels instead: k_conv12_mfma (conv1 computed inside conv2's staging, two waves per
+// task) and k_conv34_mfma (conv3's output stays in LDS).
 #include "f2_internal.h"
 
 namespace {
@@ -53,19 +54,13 @@ Dims make_dims(int rows, int channels) {
     return d;
 }
 
-// ---- conv2..4 (conv1 folded into conv2's staging): implicit GEMM on v_mfma_f32_32x32x2_f32 ----
+// ---- conv3 / conv4 for pooled inputs that do not have four rows: implicit GEMM on v_mfma_f32_32x32x2_f32 ----
 // NSPLIT waves share one task (one patch): each takes COUT/32/NSPLIT of the output tiles, so a 64-channel layer
 // keeps twice the waves per CU for the same LDS.
-// FUSE1 (conv2 only): `in` is the raw (n, Hin, Win) window tensor and the patch is *computed* - conv1 ('same', one input
-// channel, ReLU) evaluated for the 4 x 34 patch pixels from a 6 x 36 input region - instead of being read back from a
-// conv1 activation tensor: 180 KB per window less to write and 2.1x that less to stage.
-template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT, bool FUSE1 = false>
+template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT>
 __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __restrict__ in, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             int Hin, int Win, int64_t nwin,
-                                                             const float* __restrict__ w1 = nullptr,
-                                                             const float* __restrict__ b1 = nullptr) {
-    static_assert(!FUSE1 || (CIN == C1 && NSPLIT == 1 && !SAME), "the fused first layer feeds conv2");
+                                                             int Hin, int Win, int64_t nwin) {
     constexpr int PS = CIN + 4;           // LDS pitch per pixel: 16-byte aligned and conflict-free for ds_read_b128
     constexpr int PATCH = 4 * PW * PS;    // floats per wave
     constexpr int NT = COUT / 32 / NSPLIT;   // output tiles of this wave
@@ -94,44 +89,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
     const int64_t win = t2 / row_pairs;
     const int y0 = 2 * rp, x0 = 32 * xt;
 
-    if constexpr (FUSE1) {
-        constexpr int XW = PW + 2;                                   // 36 input columns, 6 input rows
-        float* xin = lds_all + TPB * PATCH + (wave / NSPLIT) * (6 * XW);
-        const float* img1 = in + win * (int64_t)Hin * Win;
-        for (int e = lane; e < 6 * XW; e += 64) {
-            const int r6 = e / XW, p6 = e - r6 * XW;
-            const int yi = y0 - 1 + r6, xi = x0 - 1 + p6;
-            xin[e] = (yi >= 0 && yi < Hin && xi >= 0 && xi < Win) ? img1[(int64_t)yi * Win + xi] : 0.f;
-        }
-        // lane = (channel quad c4, pixel group pg): 4 channels of the pixels pg, pg + 8, ... (17 of the 136)
-        const int c4 = lane & 7, pg = lane >> 3;
-        float wr[9][4], br[4];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wr[tap][q] = w1[tap * C1 + c4 * 4 + q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) br[q] = b1[c4 * 4 + q];
-        __syncthreads();
-#pragma unroll 1
-        for (int e = pg; e < 4 * PW; e += 8) {
-            const int r = e / PW, p = e - r * PW;
-            float xv[9];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) xv[dy * 3 + dx] = xin[(r + dy) * XW + p + dx];
-            float o4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float acc = 0.f;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) acc = fmaf(xv[tap], wr[tap][q], acc);   // same order as the oracle's conv1
-                o4[q] = fmaxf(acc + br[q], 0.f);
-            }
-            *reinterpret_cast<float4*>(patch + e * PS + c4 * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
-        }
-    } else {
     // stage the 4 x 34 x CIN patch with 16-byte loads (zero outside the image: 'same' padding / tile overhang)
     const float* img = in + win * (int64_t)Hin * Win * CIN;
 #pragma unroll 4
@@ -141,12 +98,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
         const int p = rem / C4, c4 = rem - p * C4;
         const int yi = y0 - PAD + r, xi = x0 - PAD + p;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef F2_KO_CNN_STAGE
         if (yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
             v = *reinterpret_cast<const float4*>(img + ((int64_t)yi * Win + xi) * CIN + c4 * 4);
-#endif
         *reinterpret_cast<float4*>(patch + (r * PW + p) * PS + c4 * 4) = v;
-    }
     }
     __syncthreads();
 
@@ -200,9 +154,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
         __builtin_amdgcn_sched_barrier(0);
     }
 
-#ifdef F2_KO_CNN_STORE
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
     if (!live) return;
     float* o = out + win * (int64_t)Hout * Wout * COUT;
 #pragma unroll
@@ -226,6 +177,123 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv3x3_mfma(const float* __rest
                     if (y < Ho && xo < Wo) o[((int64_t)y * Wout + xo) * COUT + co] = fmaxf(acc[rr][nt][q] + bv, 0.f);
                 }
             }
+        }
+    }
+}
+
+// ---- conv1 ('same', Cin = 1) + conv2 ('valid') + 2x2 max-pool in one kernel ----
+// One task = 2 conv2 output rows x 32 columns of one window (one pooled row x 16). conv1 has no tensor of its own: the
+// task's 4 x 34 x 32 conv2 input patch is *computed* - conv1 + ReLU from a 6 x 36 region of the raw window (VALU, 36 FMAs
+// per pixel and channel quad) - instead of being read back, which removed a 180 KB/window activation round trip.
+// Two waves share a task and its patch: each stages half of it and then runs the matrix-core loop for ONE of the two
+// output rows (144 MFMAs), so a CU holds 16 waves for the same LDS as 8 whole-task waves and one wave's staging hides
+// behind another's MFMAs; the rows meet through LDS for the pool.
+__global__ __launch_bounds__(512) void k_conv12_mfma(const float* __restrict__ x, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, float* __restrict__ out, int Hin,
+                                                     int Win, int64_t nwin) {
+    constexpr int PS = C1 + 4, PATCH = 4 * PW * PS, XW = PW + 2, HALF = C1 / 2, QN = HALF / 4, NIT = 9 * QN;
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = wave >> 1, r = wave & 1;                  // r: which of the task's two output rows this wave computes
+    float* patch = lds_all + pair * PATCH;
+    float* xin = lds_all + 4 * PATCH + pair * (6 * XW);
+
+    const int Ho = Hin - 2, Wo = Win - 2, Wout = Wo / 2;
+    const int row_pairs = Ho / 2, xtiles = ((Wo / 2) * 2 + 31) / 32;
+    const int64_t tasks = nwin * row_pairs * xtiles;
+    int64_t task = (int64_t)blockIdx.x * 4 + pair;
+    const bool live = task < tasks;
+    if (!live) task = tasks - 1;
+    const int xt = (int)(task % xtiles);
+    const int64_t t2 = task / xtiles;
+    const int rp = (int)(t2 % row_pairs);
+    const int64_t win = t2 / row_pairs;
+    const int y0 = 2 * rp, x0 = 32 * xt;
+
+    // raw input region rows y0-1..y0+4, cols x0-1..x0+34 (zero outside the window: conv1's 'same' padding)
+    const float* img = x + win * (int64_t)Hin * Win;
+    const int l2 = lane + 64 * r;                              // 0..127 inside the pair
+    for (int e = l2; e < 6 * XW; e += 128) {
+        const int r6 = e / XW, p6 = e - r6 * XW;
+        const int yi = y0 - 1 + r6, xi = x0 - 1 + p6;
+        xin[e] = (yi >= 0 && yi < Hin && xi >= 0 && xi < Win) ? img[(int64_t)yi * Win + xi] : 0.f;
+    }
+    // conv1 weights of this lane's channel quad
+    const int c4 = l2 & 7, pg = l2 >> 3;                       // 8 channel quads x 16 pixel groups
+    float wr[9][4], br[4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr[tap][q] = w1[tap * C1 + c4 * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) br[q] = b1[c4 * 4 + q];
+    __syncthreads();
+#pragma unroll 1
+    for (int e = pg; e < 4 * PW; e += 16) {
+        const int pr = e / PW, pc = e - pr * PW;
+        float xv[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) xv[dy * 3 + dx] = xin[(pr + dy) * XW + pc + dx];
+        float o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc = fmaf(xv[tap], wr[tap][q], acc);   // same order as the oracle's conv1
+            o4[q] = fmaxf(acc + br[q], 0.f);
+        }
+        *reinterpret_cast<float4*>(patch + e * PS + c4 * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+    __syncthreads();
+
+    // conv2 row y0 + r: lane = (pixel i, half h); operands requested one step ahead (see k_conv3x3_mfma)
+    const int i = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const float* pa0 = patch + (r * PW + i) * PS + h * HALF;
+    const float4* wq = reinterpret_cast<const float4*>(w2) + (int64_t)h * QN * C2 + i;
+    float4 av[2], bq[2];
+    auto fetch = [&](int it, int buf) {
+        const int tap = it / QN, q = it - tap * QN;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        av[buf] = *reinterpret_cast<const float4*>(pa0 + (dy * PW + dx) * PS + 4 * q);
+        bq[buf] = wq[(int64_t)tap * 2 * QN * C2 + (int64_t)q * C2];
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < NIT) fetch(it + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float a[4] = {av[cur].x, av[cur].y, av[cur].z, av[cur].w};
+        const float b[4] = {bq[cur].x, bq[cur].y, bq[cur].z, bq[cur].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // 2x2 pool: horizontal pairs sit in one lane; row 1 hands its eight pair maxima to row 0 through the (now idle) patch
+    float hm[8];
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) hm[q / 2] = fmaxf(acc[q], acc[q + 1]);
+    __syncthreads();
+    if (r == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) patch[k * 64 + lane] = hm[k];
+    }
+    __syncthreads();
+    if (r == 0 && live) {
+        const float bv = b2[i];
+        float* o = out + win * (int64_t)row_pairs * Wout * C2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = 2 * k;
+            const int px = (x0 + (q & 3) + 8 * (q >> 2) + 4 * h) >> 1;
+            const float m = fmaxf(hm[k], patch[k * 64 + lane]);
+            if (px < Wout) o[((int64_t)rp * Wout + px) * C2 + i] = fmaxf(m + bv, 0.f);
         }
     }
 }
@@ -478,9 +546,8 @@ __global__ __launch_bounds__(256) void k_dense2_softmax(const float* __restrict_
     if (labels) labels[i] = s1 > s0 ? 1 : 0;   // ties -> 0 ("falling"), Evaluating.py:87
 }
 
-template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT, bool FUSE1 = false>
-int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, float* out, int Hin, int Win, int64_t n,
-                const float* w1 = nullptr, const float* b1 = nullptr) {
+template <int CIN, int COUT, bool SAME, bool POOL, int WAVES, int NSPLIT>
+int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, float* out, int Hin, int Win, int64_t n) {
     const int Ho = SAME ? Hin : Hin - 2, Wo = SAME ? Win : Win - 2;
     const int row_pairs = POOL ? Ho / 2 : (Ho + 1) / 2;
     const int wneed = POOL ? (Wo / 2) * 2 : Wo;
@@ -488,13 +555,13 @@ int launch_conv(f2_ctx* ctx, const float* in, const float* w, const float* b, fl
     const int64_t tasks = n * row_pairs * xtiles;
     if (tasks <= 0) return F2_OK;
     constexpr int TPB = WAVES / NSPLIT;
-    constexpr size_t lds = sizeof(float) * TPB * (4 * PW * (CIN + 4) + (FUSE1 ? 6 * (PW + 2) : 0));
-    auto kern = k_conv3x3_mfma<CIN, COUT, SAME, POOL, WAVES, NSPLIT, FUSE1>;
+    constexpr size_t lds = sizeof(float) * TPB * 4 * PW * (CIN + 4);
+    auto kern = k_conv3x3_mfma<CIN, COUT, SAME, POOL, WAVES, NSPLIT>;
     if (lds > 64 * 1024)
         F2_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t blocks = (tasks + TPB - 1) / TPB;
     F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, ctx->stream, in, w, b, out, Hin, Win, n, w1, b1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, ctx->stream, in, w, b, out, Hin, Win, n);
     F2_HIP(ctx, hipGetLastError());
     return F2_OK;
 }
@@ -515,8 +582,20 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
     float* a4 = a3 + (size_t)n * d.Hp1 * d.Wp1 * C3;
     float* a5 = a4 + (size_t)n * d.flat;
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
-    // conv1 is evaluated inside conv2's patch staging
-    F2_TRY((launch_conv<C1, C2, false, true, 4, 1, true>(ctx, d_x, cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n, cnn->t(0), cnn->t(1))));
+    {
+        // conv1 + conv2 + pool (conv1 is evaluated inside conv2's patch staging)
+        const int Ho = d.H1 - 2, Wo = d.W1 - 2;
+        const int64_t tasks = n * (Ho / 2) * (((Wo / 2) * 2 + 31) / 32);
+        if (tasks > 0) {
+            constexpr size_t lds12 = sizeof(float) * 4 * (4 * PW * (C1 + 4) + 6 * (PW + 2));
+            F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv12_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12));
+            const int64_t blocks = (tasks + 3) / 4;
+            F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
+            hipLaunchKernelGGL(k_conv12_mfma, dim3((unsigned)blocks), dim3(512), lds12, ctx->stream, d_x, cnn->t(0), cnn->t(1),
+                               cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n);
+            F2_HIP(ctx, hipGetLastError());
+        }
+    }
     if (d.Hp1 == 4) {
         // four pooled rows (the reference's 11-row windows): conv3 + conv4 + pool in one kernel, conv3's output stays in LDS
         const int xtiles = (2 * d.Wp2 + T34 - 1) / T34;
