@@ -20,7 +20,7 @@ def run_bench(*args):
 
 
 def test_default_workload_line():
-    d = run_bench("--steps", "3", "--warmup", "1", "--batch", "96")
+    d = run_bench("--steps", "3", "--warmup", "1", "--batch", "96", "--corpus", "150", "--e2e-files", "8", "--cpu-sample", "8")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -34,6 +34,31 @@ def test_default_workload_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # roofline by the bytes the kernel must move, the hand-off only in moved_GBps; step-level fraction
+    assert r["kernel"] == "k_envelope" and r["moved_GBps"] >= r["achieved"]
+    need = (2 + 8 * 128) * 96 * 16000
+    assert r["step"]["algorithmic_bytes"] == need
+    assert abs(r["step"]["achieved"] - need / (d["ms_per_step"] / 1e3) / 1e9) / r["step"]["achieved"] < 0.02
+    assert d["kernels"]["k_erb_filterbank"]["f64_TFLOPps"] > 0
+    # the other configurations ride along in the default single-GPU line
+    b = d["blocks"]
+    assert set(b) >= {"cfg3_fft_f64", "cfg5", "cfg5_ragged", "cfg4", "end_to_end"}
+    assert b["cfg3_fft_f64"]["value"] > 0 and b["cfg5"]["scaling"] == "strong" and b["cfg5_ragged"]["value"] > 0
+    assert 0 < b["cfg4"]["cnn"]["frac"] < 1 and b["cfg4"]["cpu_baseline"]["value"] > 0
+    e = b["end_to_end"]
+    assert e["two_commands_audio_s_per_s"] > 0 and e["one_pass_audio_s_per_s"] > 0 and e["cpu_baseline"]["value"] > 0
+
+
+def test_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` as typed (both ranks on device 0): strong-scaling cfg5 line from the host-side merge."""
+    os.environ["F2CNN_BENCH_ONE_DEVICE"] = "1"
+    try:
+        d = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--corpus", "64", "--no-cpu-baseline", "--no-blocks")
+    finally:
+        del os.environ["F2CNN_BENCH_ONE_DEVICE"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["workload"].startswith("cfg5:")
+    assert [p["audio_s_per_step"] for p in d["per_rank"]] == [32.0, 32.0]
+    assert abs(d["value"] - 64 * 2 / max(p["elapsed_s"] for p in d["per_rank"])) / d["value"] < 0.02
 
 
 def test_cnn_workload_line():

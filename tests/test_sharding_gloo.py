@@ -68,3 +68,41 @@ def test_two_ranks_cover_the_corpus_once():
     for i, f in enumerate(files):
         wave = bench.synth_batch(2029, i, 1, 800)[0]
         assert np.isclose(merged[f], orc.filter_and_envelope(wave, coefs, True, 50).sum(), rtol=1e-12)
+
+
+def _run_bench(*args, launcher=None):
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), *args]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines           # stdout carries the JSON line and nothing else
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_and_merges_on_the_host():
+    """`python bench.py --gpus 2` as the driver types it: the parent starts two fresh rank processes, they shard the
+    cfg5 corpus r::G, meet over gloo and rank 0 prints one merged line (--dry-run: everything but the device work)."""
+    import bench
+    one = _run_bench("--dry-run", "--gpus", "1", "--workload", "cfg5", "--corpus", "11", "--samples", "640", "--steps", "2")
+    two = _run_bench("--dry-run", "--gpus", "2", "--corpus", "11", "--samples", "640", "--steps", "2")   # default N>1 = cfg5
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["workload"].startswith("cfg5:")
+    assert [r["utterances"] for r in two["per_rank"]] == [6, 5]            # files[r::G]
+    # strong scaling: the same corpus whatever the number of ranks
+    assert two["checksum"] == one["checksum"] == int(bench.synth_batch(2029, 0, 11, 640).astype(np.int64).sum())
+    # value = all ranks' audio-seconds / MAX elapsed over ranks
+    total_s = sum(r["samples_per_step"] for r in two["per_rank"]) / 16000 * 2
+    assert abs(two["value"] - total_s / max(r["elapsed"] for r in two["per_rank"])) < 0.06
+
+
+def test_bench_under_torchrun_takes_the_same_path():
+    two = _run_bench("--dry-run", "--gpus", "2", "--workload", "cfg5r", "--corpus", "9", "--steps", "1", launcher=2)
+    import bench
+    lens = bench.ragged_lengths(2029, 9)
+    assert two["n_gpus"] == 2 and [r["samples_per_step"] for r in two["per_rank"]] == [int(lens[0::2].sum()), int(lens[1::2].sum())]
+    assert lens.min() >= 16000 and lens.max() <= 64000
