@@ -44,17 +44,24 @@ static int prof_event(f2_ctx* ctx, hipEvent_t* ev) {
 
 int f2_prof_begin(f2_ctx* ctx, int kernel_id) {
     if (!ctx->prof_on) return F2_OK;
+    auto& spans = ctx->prof[kernel_id];
+    if (!spans.empty() && !spans.back().closed) {   // left open by a launch that returned an error
+        ctx->prof_pool.push_back(spans.back().first);
+        ctx->prof_pool.push_back(spans.back().second);
+        spans.pop_back();
+    }
     hipEvent_t a, b;
     F2_TRY(prof_event(ctx, &a));
     F2_TRY(prof_event(ctx, &b));
-    ctx->prof[kernel_id].push_back({a, b});
+    spans.push_back({a, b, false});
     F2_HIP(ctx, hipEventRecord(a, ctx->stream));
     return F2_OK;
 }
 
 int f2_prof_end(f2_ctx* ctx, int kernel_id) {
-    if (!ctx->prof_on) return F2_OK;
+    if (!ctx->prof_on || ctx->prof[kernel_id].empty()) return F2_OK;
     F2_HIP(ctx, hipEventRecord(ctx->prof[kernel_id].back().second, ctx->stream));
+    ctx->prof[kernel_id].back().closed = true;
     return F2_OK;
 }
 
@@ -270,12 +277,15 @@ int f2_prof_get(f2_ctx* ctx, int kernel_id, int* launches, float* total_ms) {
     F2_CHECK(ctx, kernel_id >= 0 && kernel_id < F2_K_COUNT, F2_ERR_INVALID, "bad kernel id %d", kernel_id);
     F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float sum = 0.f;
+    int closed = 0;
     for (auto& pr : ctx->prof[kernel_id]) {
+        if (!pr.closed) continue;
         float ms = 0.f;
         F2_HIP(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
         sum += ms;
+        ++closed;
     }
-    if (launches) *launches = (int)ctx->prof[kernel_id].size();
+    if (launches) *launches = closed;
     if (total_ms) *total_ms = sum;
     return F2_OK;
 }

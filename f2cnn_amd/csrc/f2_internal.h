@@ -40,7 +40,11 @@ struct f2_ctx {
     std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
     std::vector<double> coefs_host;     // what ctx->coefs currently holds
     bool prof_on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[F2_K_COUNT];  // (start, stop) per launch
+    struct prof_span {
+        hipEvent_t first, second;   // start, stop
+        bool closed;                // stop has been recorded (false when the launch in between failed)
+    };
+    std::vector<prof_span> prof[F2_K_COUNT];                         // one span per launch group
     std::vector<hipEvent_t> prof_pool;                               // recycled events
     f2_scratch flags;      // small device words (error flags)
     int* host_flags = nullptr;  // pinned mirror
@@ -83,7 +87,8 @@ int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C);
         if (rc_ != F2_OK) return rc_; \
     } while (0)
 
-// RAII-free profiling bracket: F2_PROF_BEGIN before the launch(es) of one kernel id, F2_PROF_END after.
+// Profiling bracket: f2_prof_begin before the launch(es) of one kernel id, f2_prof_end after. A span whose launch
+// failed in between is never closed: it is recycled by the next f2_prof_begin / f2_prof_reset and skipped by f2_prof_get.
 int f2_prof_begin(f2_ctx* ctx, int kernel_id);
 int f2_prof_end(f2_ctx* ctx, int kernel_id);
 

@@ -6,8 +6,8 @@ writes of the previous one run on threads (NumPy file I/O releases the GIL) whil
 batch. Results are written by the caller's `save` exactly as the reference names and formats them.
 """
 import os
-import sys
 import threading
+import weakref
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy
@@ -44,35 +44,44 @@ def run_batches(items, load, compute, save, batch=32, readers=4, writers=None, m
 class ArrayPool:
     """Recycles the large host arrays of the file drivers. A fresh numpy.empty of half a gigabyte is page-faulted in
     by the device-to-host copy that fills it (about 30 ms per 16-file batch, more than the copy and the kernels
-    together); an array whose pages are already mapped is not. An owner array is free again when nothing but the
-    pool refers to it: every view handed out (and every view of a view) holds a reference to its owner."""
+    together); a buffer whose pages are already mapped is not.
 
-    def __init__(self, keep=6):
-        self._owners = []
+    Every array handed out is a lease on one pooled buffer. The lease is tracked explicitly: the array is built over
+    a memoryview of the buffer, so every view derived from it (slices, reshapes, the per-file matrices the writer
+    threads hold) keeps THAT array alive through its `.base`, and a weakref.finalize on it returns the buffer to the
+    pool when the last of them is gone. `alloc(nbytes)` may supply page-locked buffers (any writable object with the
+    buffer protocol)."""
+
+    def __init__(self, keep=6, alloc=None):
+        self._buffers = []          # [buffer, nbytes, busy]
         self._lock = threading.Lock()
+        self._alloc = alloc or (lambda nbytes: numpy.empty(nbytes, numpy.uint8))
         self.keep = keep
+
+    def _release(self, entry):
+        with self._lock:
+            entry[2] = False
+            idle = [e for e in self._buffers if not e[2]]
+            if len(self._buffers) > self.keep and len(idle) > 1:   # drop the smallest buffer nobody uses
+                victim = min(idle, key=lambda e: e[1])
+                self._buffers = [e for e in self._buffers if e is not victim]
 
     def empty(self, count, dtype=numpy.float64):
         """Uninitialised 1-D array of `count` elements backed by a pooled buffer."""
         dtype = numpy.dtype(dtype)
         nbytes = int(count) * dtype.itemsize
         with self._lock:
-            best = None
-            for i in range(len(self._owners)):
-                o = self._owners[i]
-                # references: the list, `o`, getrefcount's argument
-                if o.nbytes >= nbytes and sys.getrefcount(o) <= 3 and (best is None or o.nbytes < best.nbytes):
-                    best = o
-                del o
-            if best is None:
-                best = numpy.empty(max(nbytes + nbytes // 8, 1 << 20), numpy.uint8)
-                self._owners.append(best)
-                if len(self._owners) > self.keep:   # drop the smallest buffer nobody uses
-                    idle = [o for o in self._owners if o is not best and sys.getrefcount(o) <= 4]
-                    if idle:
-                        victim = min(idle, key=lambda o: o.nbytes)
-                        self._owners = [o for o in self._owners if o is not victim]
-            return best[:nbytes].view(dtype)
+            fits = [e for e in self._buffers if not e[2] and e[1] >= nbytes]
+            if fits:
+                entry = min(fits, key=lambda e: e[1])
+            else:
+                size = max(nbytes + nbytes // 8, 1 << 20)
+                entry = [self._alloc(size), size, False]
+                self._buffers.append(entry)
+            entry[2] = True
+        arr = numpy.frombuffer(memoryview(entry[0]).cast("B")[:nbytes], dtype=dtype)
+        weakref.finalize(arr, self._release, entry)
+        return arr
 
 
 host_pool = ArrayPool()

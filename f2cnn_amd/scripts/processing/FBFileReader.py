@@ -4,6 +4,24 @@ big-endian float32 per frame (F1..F4, B1..B4 in kHz). Host-side; SURVEY section 
 import numpy
 
 
+def round_half_even_decimal(values, digits):
+    """Python's round(x, digits) for every element of a float64 array.
+
+    The reference rounds each value with the built-in round() on a Python float (:44-47), which rounds the exact
+    decimal expansion of the binary value; numpy.round computes rint(x * 10^digits) / 10^digits, and the product can
+    land on the other side of a tie. The two agree unless x * 10^digits is within rounding distance of k + 0.5, so
+    only those elements (none in a typical file) take the per-element path."""
+    values = numpy.asarray(values, dtype=numpy.float64)
+    out = numpy.round(values, digits)
+    scaled = numpy.abs(values) * 10.0 ** digits
+    near_tie = numpy.abs(scaled - numpy.floor(scaled) - 0.5) < 1e-6
+    if near_tie.any():
+        flat, src = out.reshape(-1), values.reshape(-1)
+        for i in numpy.flatnonzero(near_tie.reshape(-1)):
+            flat[i] = round(float(src[i]), digits)
+    return out
+
+
 def ExtractFBFile(fbFilename, verbose=False):
     """(nFrame, 8) float64 matrix in Hz rounded to 2 decimals, and the sampling period (fixed 10000 us like the
     reference, which ignores the header field because one VTR file carries a wrong value, :22-24)."""
@@ -23,27 +41,43 @@ def ExtractFBFile(fbFilename, verbose=False):
             data = numpy.fromfile(fbFile, dtype='>f4', count=nFrame * 8)
         if data.size != nFrame * 8:
             raise ValueError("{}: truncated .FB file ({} of {} values)".format(fbFilename, data.size, nFrame * 8))
-        # float32 -> Python float -> *1000 -> round(.., 2), element by element in the reference (:44-47)
-        return numpy.round(data.astype(numpy.float64).reshape(nFrame, 8) * 1000, 2), sampPeriod
+        # kHz float32 -> float64 -> Hz, rounded to 2 decimals the way the built-in round() does
+        return round_half_even_decimal(data.astype(numpy.float64).reshape(nFrame, 8) * 1000, 2), sampPeriod
     except FileNotFoundError:
         print("No .FB formant data file.")
         return None, 0
 
 
 def GetFormantFrequencies(fbFilename, formant):
-    """Frequencies (Hz) of formant 1..4 for every frame, and the sampling period."""
+    """Track of formant 1..4 in Hz (one value per frame) and the sampling period; (None, None) without a file."""
     matrix, sampPeriod = ExtractFBFile(fbFilename)
-    if matrix is not None:
-        return matrix[:, formant - 1], sampPeriod
-    return None, None
+    return (None, None) if matrix is None else (matrix[:, formant - 1], sampPeriod)
+
+
+def frame_windows(track, timepoints, radius, samples_per_frame):
+    """Rows of 2*radius+1 consecutive frames of `track`, one per WAV sample index in `timepoints`: the window of
+    timepoint t starts at frame int(t / samples_per_frame - radius) (reference :69-89). A window that would start
+    before frame 0, or whose end int(t / samples_per_frame + radius) + 1 reaches len(track), ends the program as the
+    reference does."""
+    track = numpy.asarray(track)
+    t = numpy.asarray(timepoints, dtype=numpy.float64) / samples_per_frame
+    first = numpy.trunc(t - radius).astype(numpy.int64)
+    last = numpy.trunc(t + radius).astype(numpy.int64) + 1
+    width = 2 * radius + 1
+    bad = (first < 0) | (last >= len(track))
+    if bad.any():
+        i = int(numpy.flatnonzero(bad)[0])
+        print("ERROR: formant window [{}, {}) of timepoint {} (radius {}) is outside the {} frames of the track".format(
+            int(first[i]), int(last[i]), int(numpy.asarray(timepoints).reshape(-1)[i]), radius, len(track)))
+        exit(-1)
+    if len(first) == 0 or len(track) < width:
+        return numpy.zeros((len(first), width), dtype=track.dtype)
+    return numpy.lib.stride_tricks.sliding_window_view(track, width)[first]
 
 
 def GetFromantFrequenciesAround(array, timepoint, radius, wavToFormant):
-    """The 2*radius+1 frame values centred on WAV sample `timepoint` (reference :69-89; same name, typo included)."""
-    start, end = timepoint / wavToFormant - radius, timepoint / wavToFormant + radius
-    start, end = int(start), int(end) + 1
-    if start < 0 or end >= len(array):
-        print("ERROR: WRONG RANGE IN GETFORMANTFREQUENCIESAROUND IN ARRAY OF LEN:\n", len(array), "\nAT TIME AND RADIUS",
-              timepoint, radius, "START", start, "END", end)
-        exit(-1)
+    """The 2*radius+1 frame values centred on WAV sample `timepoint` (the reference's name, typo included)."""
+    start = int(timepoint / wavToFormant - radius)
+    end = int(timepoint / wavToFormant + radius) + 1
+    frame_windows(array, [timepoint], radius, wavToFormant)          # range check (exits like the reference)
     return array[start:end]

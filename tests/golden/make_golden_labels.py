@@ -50,6 +50,18 @@ def main():
             f2, _ = ref_fb.GetFormantFrequencies(path, 2)
             out[f"fb_{tag}_f2"] = f2
             out[f"fb_{tag}_around"] = np.array(ref_fb.GetFromantFrequenciesAround(f2, 4800, 5, 160.0))
+        # rounding rule of the reader (built-in round(d * 1000, 2) per value): 500 frames of random values plus the
+        # float32 numbers closest to two-decimal ties x.xx5 Hz, from both sides
+        rng = np.random.default_rng(3)
+        ties = (rng.integers(20000, 400000, size=2000) + 0.5) / 100.0 / 1000.0          # kHz
+        t32 = ties.astype(np.float32)
+        near = np.concatenate([np.nextafter(t32[:667], np.float32(0)), t32[667:1334], np.nextafter(t32[1334:], np.float32(10))])
+        frames = np.concatenate([near, rng.uniform(0.05, 4.0, size=2000).astype(np.float32)]).astype(np.float32).reshape(-1, 8)
+        path = os.path.join(tmp, "t.FB")
+        with open(path, "wb") as f:
+            f.write(fb_bytes(frames))
+        out["fb_t_frames_f32"] = frames
+        out["fb_t_matrix"] = ref_fb.ExtractFBFile(path)[0]
         phn = os.path.join(tmp, "x.PHN")
         with open(phn, "w") as f:
             f.write(PHN_TEXT)

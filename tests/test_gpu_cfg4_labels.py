@@ -1,0 +1,157 @@
+"""BASELINE config 4 at full size: `cnn eval` of the 8 x 1 s corpus (seed 2028, Glorot weights seed 7) through
+f2_eval_batch, ALL 113 920 rising/falling labels against the oracle chain (reference Evaluating.py:42-87), with no
+hidden margin: every window whose label differs must be a rounding-level tie according to the float64-accumulating
+referee (oracle cnn_forward(dtype=float64)), and the number of such windows is printed.
+
+Two inputs can make a label differ: the float32 summation order inside the CNN (bound: CNN_TIE, the tolerance the
+scores themselves are held to) and, with the float32 FFT, the 1e-7-level envelope differences that the log min-max
+normalisation amplifies for the smallest values of a window (bound: PIPE_TIE_F32FFT). The reference-precision
+pipeline (float64 FFT) is held to the CNN bound alone.
+"""
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+
+import f2cnn_oracle as orc
+from conftest import ROOT
+from f2cnn_amd import _lib
+from f2cnn_amd.gammatone import filters
+from f2cnn_amd.model import F2CNNModel
+
+pytestmark = pytest.mark.gpu
+
+CNN_TIE = 2e-5            # |s1 - s0| of the referee below which two float32 evaluations may order the scores differently
+PIPE_TIE_F32FFT = 1e-3    # same, when the envelopes come from the float32 FFT (score tolerance of that pipeline: 5e-4)
+B, N, NB = 8, 16000, 16000 - 1760
+
+
+def _oracle_task(args):
+    """Scores of windows [lo, hi) of utterance u of the cfg4 corpus through the whole oracle chain."""
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import f2cnn_oracle as o
+    from threadpoolctl import threadpool_limits
+    u, lo, hi, shift = args
+    with threadpool_limits(limits=1):        # the pool owns the cores: one BLAS thread per process
+        return _oracle_scores(o, u, lo, hi, shift)
+
+
+def cfg4_weights(o, shift):
+    """Glorot seed 7, zero biases (BASELINE cfg4); `shift` moves the rising/falling boundary (dense2 bias)."""
+    w = o.glorot_weights(7)
+    w["dense2_b"] = np.array([0.5 * shift, -0.5 * shift], np.float32)
+    return w
+
+
+def _oracle_scores(o, u, lo, hi, shift):
+    wave = o.synth_utterance(2028 + u, N)
+    coefs = o.make_erb_filters(16000, o.centre_freqs(16000, 128, 100))
+    env = o.filter_and_envelope(wave, coefs, False)
+    w = o.gather_windows(env, o.eval_window_centers(N)[lo:hi])
+    for i in range(w.shape[0]):
+        w[i] = o.normalize_input(w[i])
+    return u, lo, o.cnn_forward(w, cfg4_weights(o, shift))
+
+
+def oracle_chain(shift):
+    cores = min(16, len(os.sched_getaffinity(0)))
+    parts = 8
+    edges = np.linspace(0, NB, parts + 1).astype(int)
+    tasks = [(u, int(a), int(b), shift) for u in range(B) for a, b in zip(edges[:-1], edges[1:])]
+    out = np.empty((B, NB, 2), np.float32)
+    with mp.get_context("spawn").Pool(cores) as pool:
+        for k, (u, lo, s) in enumerate(pool.imap_unordered(_oracle_task, tasks)):
+            out[u, lo:lo + len(s)] = s
+            print(f"oracle chain: {k + 1}/{len(tasks)} window ranges done", flush=True)
+    return out.reshape(B * NB, 2)
+
+
+@pytest.fixture(scope="module")
+def oracle_scores():
+    """{variant: (dense2 bias shift, oracle scores)}. 'glorot7' is the configuration as BASELINE states it; with those
+    weights every window of the corpus scores 'rising', so 'balanced' moves the decision boundary to the median
+    logit gap of the corpus (half the windows on each side, and thousands of them close to it)."""
+    base = oracle_chain(0.0)
+    gap = np.log(base[:, 1].astype(np.float64)) - np.log(base[:, 0].astype(np.float64))
+    shift = float(np.float32(np.median(gap)))
+    return {"glorot7": (0.0, base), "balanced": (shift, oracle_chain(shift))}
+
+
+def referee_margins(windows_idx, shift):
+    """|s1 - s0| of the float64 referee for the given flat window indices, on the oracle's own window tensors."""
+    coefs = orc.make_erb_filters(16000, orc.centre_freqs(16000, 128, 100))
+    w64 = cfg4_weights(orc, shift)
+    out = np.empty(len(windows_idx))
+    cache = {}
+    for k, flat in enumerate(windows_idx):
+        u, i = divmod(int(flat), NB)
+        if u not in cache:
+            cache[u] = orc.filter_and_envelope(orc.synth_utterance(2028 + u, N), coefs, False)
+        w = orc.normalize_input(orc.gather_windows(cache[u], orc.eval_window_centers(N)[i:i + 1])[0])
+        s = orc.cnn_forward_referee(w[None], w64)[0]
+        out[k] = abs(s[1] - s[0])
+    return out
+
+
+def gpu_eval(precision, shift):
+    ctx = _lib.default_context()
+    m = F2CNNModel.glorot(7)
+    np.testing.assert_array_equal(m.tensors["conv2_w"], orc.glorot_weights(7)["conv2_w"])   # same synthetic weights
+    m = F2CNNModel(cfg4_weights(orc, shift))
+    waves = np.concatenate([orc.synth_utterance(2028 + u, N) for u in range(B)])
+    offsets = np.arange(B + 1, dtype=np.int64) * N
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    scores = np.empty((B * NB, 2), np.float32)
+    labels = np.empty(B * NB, np.uint8)
+    ctx.eval_batch(m.handle(ctx), waves, _lib.WAVE_I16, offsets, coefs, B, 128, False, 0.0, precision, 5, 160, scores,
+                   labels, _lib.MEM_HOST)
+    return scores, labels
+
+
+@pytest.mark.parametrize("variant", ["glorot7", "balanced"])
+@pytest.mark.parametrize("precision,tie,score_tol", [(_lib.FFT_F64, CNN_TIE, 2e-5), (_lib.FFT_F32, PIPE_TIE_F32FFT, 5e-4)])
+def test_all_cfg4_labels(oracle_scores, precision, tie, score_tol, variant):
+    shift, oracle_scores = oracle_scores[variant]
+    scores, labels = gpu_eval(precision, shift)
+    assert labels.shape == (113920,)
+    np.testing.assert_array_equal(labels, (scores[:, 1] > scores[:, 0]).astype(np.uint8))   # Evaluating.py:87, ties -> 0
+    assert np.abs(scores - oracle_scores).max() <= score_tol
+    ref_labels = orc.labels_from_scores(oracle_scores)
+    differ = np.flatnonzero(labels != ref_labels)
+    near = int((np.abs(oracle_scores[:, 1] - oracle_scores[:, 0]) <= tie).sum())
+    name = "f64" if precision == _lib.FFT_F64 else "f32"
+    print(f"\ncfg4 labels, {variant} weights, {name} FFT: {len(labels) - len(differ)} of {len(labels)} identical, "
+          f"{len(differ)} differ; {near} windows have an oracle margin <= {tie:g}; {int(ref_labels.sum())} rising")
+    if variant == "balanced":
+        assert 0.3 < ref_labels.mean() < 0.7          # both classes occur: the comparison is not vacuous
+    if len(differ):
+        margins = referee_margins(differ, shift)
+        print(f"referee (float64) margins of the differing windows: max {margins.max():.3g}")
+        assert margins.max() <= tie, "a label differs on a window the float64 referee decides clearly"
+    assert len(differ) <= near + 1
+
+
+def test_cnn_alone_on_identical_windows():
+    """K4 against the oracle CNN on the SAME 11x128 window tensors (the GPU's own windows of utterance 0, every 7th):
+    only the float32 summation order differs, so every differing label must be a referee tie at CNN_TIE."""
+    ctx = _lib.default_context()
+    m = F2CNNModel.glorot(7)
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    env = filters.erb_filterbank(orc.synth_utterance(2028, N), coefs, ctx)
+    from f2cnn_amd.scripts.processing.EnvelopeExtraction import ExtractEnvelopeFromMatrix
+    env = ExtractEnvelopeFromMatrix(env, False)
+    centers = orc.eval_window_centers(N)[::7]
+    x = np.empty((len(centers), 11, 128), np.float32)
+    ctx.gather_windows(env, 128, N, centers, len(centers), 5, 160, True, x, _lib.MEM_HOST)
+    scores, labels = m.predict_labels(x)
+    ref = orc.cnn_forward(x, dict(m.tensors))
+    np.testing.assert_allclose(scores, ref, atol=2e-5)
+    differ = np.flatnonzero(labels != orc.labels_from_scores(ref))
+    print(f"\nCNN alone: {len(differ)} of {len(labels)} labels differ; max |score diff| {np.abs(scores - ref).max():.2e}")
+    if len(differ):
+        r = orc.cnn_forward_referee(x[differ], dict(m.tensors))
+        assert np.abs(r[:, 1] - r[:, 0]).max() <= CNN_TIE

@@ -101,23 +101,35 @@ def test_cnn_chunking_is_invisible():
     np.testing.assert_array_equal(s[-70:], m.predict(x[-70:]))
 
 
-def test_torch_state_dict_conversion():
+@pytest.mark.parametrize("rows,channels,n", [(11, 128, 1024), (13, 40, 300), (10, 100, 300), (11, 64, 300)])
+def test_torch_state_dict_conversion(rows, channels, n):
+    """Independent evidence for the (unpinned) CNN oracle: the same network evaluated by PyTorch on the CPU
+    (Conv2d / max_pool2d / Linear, NCHW) against the oracle restatement AND against K4, >= 1000 windows of the
+    reference's 11 x 128 shape plus other row / channel counts."""
     import torch
     torch.manual_seed(0)
+    hp2, wp2 = ((rows - 2) // 2 - 2) // 2, ((channels - 2) // 2 - 2) // 2
     net = torch.nn.ModuleDict({
         "conv1": torch.nn.Conv2d(1, 32, 3, padding=1), "conv2": torch.nn.Conv2d(32, 32, 3),
         "conv3": torch.nn.Conv2d(32, 64, 3, padding=1), "conv4": torch.nn.Conv2d(64, 64, 3),
-        "dense1": torch.nn.Linear(1920, 516), "dense2": torch.nn.Linear(516, 2)})
-    x = torch.rand(9, 1, 11, 128)
+        "dense1": torch.nn.Linear(64 * hp2 * wp2, 516), "dense2": torch.nn.Linear(516, 2)})
+    x = torch.rand(n, 1, rows, channels)
     with torch.no_grad():
         h = torch.relu(net["conv2"](torch.relu(net["conv1"](x))))
         h = torch.nn.functional.max_pool2d(h, 2)
         h = torch.relu(net["conv4"](torch.relu(net["conv3"](h))))
         h = torch.nn.functional.max_pool2d(h, 2).flatten(1)
         ref = torch.softmax(net["dense2"](torch.relu(net["dense1"](h))), dim=1).numpy()
-    m = F2CNNModel.from_torch_state_dict(net.state_dict())
-    np.testing.assert_allclose(m.predict(x[:, 0].numpy()), ref, atol=2e-5)
-    np.testing.assert_allclose(orc.cnn_forward(x[:, 0].numpy(), oracle_weights(m)), ref, atol=2e-5)
+    m = F2CNNModel.from_torch_state_dict(net.state_dict(), rows, channels)
+    got = m.predict(x[:, 0].numpy())
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+    o = orc.cnn_forward(x[:, 0].numpy(), oracle_weights(m))
+    np.testing.assert_allclose(o, ref, atol=2e-5)
+    # labels: torch, oracle and K4 agree wherever the float64 referee's margin is above the float32 rounding level
+    r = orc.cnn_forward_referee(x[:, 0].numpy(), oracle_weights(m))
+    clear = np.abs(r[:, 1] - r[:, 0]) > 2e-5
+    for s in (got, o, ref):
+        np.testing.assert_array_equal((s[:, 1] > s[:, 0])[clear], (r[:, 1] > r[:, 0])[clear])
 
 
 def test_eval_pipeline_cfg4_shape(tmp_path, monkeypatch):
@@ -133,8 +145,13 @@ def test_eval_pipeline_cfg4_shape(tmp_path, monkeypatch):
     assert chan_relerr(env, env_ref) <= 1e-5
     ref = orc.cnn_forward(orc.eval_input_tensor(env_ref), oracle_weights(m))
     np.testing.assert_allclose(scores, ref, atol=5e-4)
-    decided = np.abs(ref[:, 1] - ref[:, 0]) > 2e-3
-    np.testing.assert_array_equal(labels[decided], orc.labels_from_scores(ref)[decided])
+    # labels: identical, or a tie at the float32-FFT pipeline's rounding level for the float64 referee
+    # (same rule as tests/test_gpu_cfg4_labels.py, which runs all 113 920 windows of the full configuration)
+    differ = np.flatnonzero(labels != orc.labels_from_scores(ref))
+    if len(differ):
+        r = orc.cnn_forward_referee(orc.eval_input_tensor(env_ref)[differ], oracle_weights(m))
+        assert np.abs(r[:, 1] - r[:, 0]).max() <= 1e-3
+    assert len(differ) <= 0.01 * len(labels)
     # too short for a single window: no scores, no error
     s2, l2 = Evaluating.EvaluateOneWavArray(wave[:1700], 16000, model=m)
     assert s2.shape == (0, 2) and l2.shape == (0,)

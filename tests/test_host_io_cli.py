@@ -29,6 +29,81 @@ def test_sphere_and_riff_roundtrip(tmp_path):
         wavio.read_audio(tmp_path / "d.WAV")
 
 
+def nist_header(fields, header_size=1024):
+    """A NIST SPHERE header assembled from the format's grammar (not through wavio.write_sphere): the magic line
+    'NIST_1A', the header size right-justified in 7 characters, then `name -type value` lines (type -i integer,
+    -r real, -sN string of N characters), 'end_head', padded with blanks to the declared size."""
+    lines = [b"NIST_1A", b"%7d" % header_size]
+    for name, value in fields:
+        if isinstance(value, int):
+            lines.append(b"%s -i %d" % (name.encode(), value))
+        elif isinstance(value, float):
+            lines.append(b"%s -r %f" % (name.encode(), value))
+        else:
+            lines.append(b"%s -s%d %s" % (name.encode(), len(value), value.encode()))
+    head = b"\n".join(lines + [b"end_head"]) + b"\n"
+    assert len(head) <= header_size
+    return head.ljust(header_size, b" ")
+
+
+TIMIT_FIELDS = [("database_id", "TIMIT"), ("database_version", "1.0"), ("utterance_id", "cjf0_sa1"),
+                ("channel_count", 1), ("sample_count", 0), ("sample_rate", 16000), ("sample_min", -2191),
+                ("sample_max", 2790), ("sample_n_bytes", 2), ("sample_byte_format", "01"), ("sample_sig_bits", 16)]
+
+
+def fields_with(**over):
+    out = []
+    for k, v in TIMIT_FIELDS:
+        v = over.pop(k, v)
+        if v is not None:
+            out.append((k, v))
+    return out + list(over.items())
+
+
+def test_sphere_files_built_from_the_header_grammar(tmp_path):
+    """What the reference reads through sphfile.SPHFile (GammatoneFiltering.py:33-38): TIMIT-style little-endian
+    headers, big-endian bodies, larger headers, a missing sample_count, two channels; compressed bodies are refused."""
+    x = (np.random.default_rng(1).standard_normal(3001) * 5000).astype(np.int16)
+    p = tmp_path / "x.WAV"
+    # 1. a TIMIT header as the corpus ships it (string fields with their lengths, min/max fields the reader ignores)
+    p.write_bytes(nist_header(fields_with(sample_count=len(x))) + x.astype("<i2").tobytes())
+    rate, y = wavio.read_audio(p)
+    assert rate == 16000 and y.dtype == np.int16 and y.flags["C_CONTIGUOUS"]
+    np.testing.assert_array_equal(y, x)
+    # 2. big-endian samples (sample_byte_format 10), 8 kHz, 2048-byte header, a string value with blanks
+    p.write_bytes(nist_header(fields_with(sample_count=len(x), sample_byte_format="10", sample_rate=8000,
+                                          speaking_mode="read speech"), 2048) + x.astype(">i2").tobytes())
+    rate, y = wavio.read_audio(p)
+    assert rate == 8000
+    np.testing.assert_array_equal(y, x)
+    # 3. no sample_count: everything after the header
+    p.write_bytes(nist_header(fields_with(sample_count=None)) + x.astype("<i2").tobytes())
+    np.testing.assert_array_equal(wavio.read_audio(p)[1], x)
+    # 4. sample_count smaller than the body: trailing bytes are not samples
+    p.write_bytes(nist_header(fields_with(sample_count=1000)) + x.astype("<i2").tobytes())
+    np.testing.assert_array_equal(wavio.read_audio(p)[1], x[:1000])
+    # 5. two interleaved channels: the first one (TIMIT is mono; sample_count counts frames)
+    two = np.stack([x, -x], axis=1)
+    p.write_bytes(nist_header(fields_with(sample_count=len(x), channel_count=2, sample_byte_format="10")) +
+                  two.astype(">i2").tobytes())
+    np.testing.assert_array_equal(wavio.read_audio(p)[1], x)
+    # 6. shorten-compressed and mu-law bodies are refused loudly, as is a header that is not SPHERE at all
+    for coding, nbytes in (("pcm,embedded-shorten-v2.00", 2), ("ulaw", 1), ("pcm", 1), ("pcm", 4)):
+        p.write_bytes(nist_header(fields_with(sample_count=len(x), sample_coding=coding, sample_n_bytes=nbytes)) +
+                      x.astype("<i2").tobytes())
+        with pytest.raises(ValueError):
+            wavio.read_audio(p)
+    p.write_bytes(b"NIST_1B\n   1024\n".ljust(1024) + x.tobytes())
+    with pytest.raises(ValueError):
+        wavio.read_audio(p)
+    # 7. the writer used for synthetic corpora emits a header this grammar accepts, byte for byte
+    wavio.write_sphere(p, 16000, x)
+    raw = p.read_bytes()
+    want = nist_header([("channel_count", 1), ("sample_count", len(x)), ("sample_rate", 16000), ("sample_n_bytes", 2),
+                        ("sample_byte_format", "01"), ("sample_sig_bits", 16), ("sample_coding", "pcm")])
+    assert raw[:1024] == want and raw[1024:] == x.astype("<i2").tobytes()
+
+
 def test_config_defaults_and_file(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     c = config.F2Config()
@@ -142,21 +217,36 @@ def test_iopipe_order_and_completeness():
 
 
 def test_array_pool_recycles_only_unreferenced_owners():
+    import gc
     from f2cnn_amd.iopipe import ArrayPool
     pool = ArrayPool(keep=3)
     a = pool.empty(1000)
-    owner_a = a.base
-    addr_a = owner_a.ctypes.data
-    del owner_a
+    addr_a = a.ctypes.data
+    a[:] = 7.0                                              # writable
     b = pool.empty(500)
-    assert b.base.ctypes.data != addr_a                    # a is alive: a second owner
-    view = a[10:20].reshape(2, 5)                           # a view of a view keeps the owner busy
+    assert b.ctypes.data != addr_a                          # a is alive: a second buffer
+    view = a[10:20].reshape(2, 5)                           # a view of a view keeps the lease
+    assert view.base is not None
     del a
+    gc.collect()
     c = pool.empty(800)
-    assert c.base.ctypes.data != addr_a
+    assert c.ctypes.data != addr_a
     del view
+    gc.collect()
     d = pool.empty(900, dtype=np.float32)
-    assert d.base.ctypes.data == addr_a and d.dtype == np.float32 and d.shape == (900,)
+    assert d.ctypes.data == addr_a and d.dtype == np.float32 and d.shape == (900,)
     for _ in range(10):                                     # the pool does not grow without bound
         pool.empty(100)
-    assert len(pool._owners) <= 4
+    gc.collect()
+    assert len(pool._buffers) <= 4
+    # leases released from other threads (the .npy writers) are seen by the allocating thread
+    import threading
+    e = pool.empty(2000)
+    addr_e = e.ctypes.data
+    t = threading.Thread(target=lambda v: None, args=(e[:5],))
+    del e
+    t.start()
+    t.join()
+    del t
+    gc.collect()
+    assert pool.empty(2000).ctypes.data == addr_e

@@ -39,6 +39,42 @@ def test_fb_reader_matches_reference(gl, tag, tmp_path):
         FBFileReader.GetFromantFrequenciesAround(f2, 100, 5, 160.0)
 
 
+def test_fb_rounding_is_the_builtin_round(gl, tmp_path):
+    """4000 values (float32 neighbours of two-decimal ties + random) against the reference reader's output, and the
+    rounding helper against round() on doubles where numpy.round lands on the other side of the tie."""
+    p = str(tmp_path / "t.FB")
+    write_fb(p, gl["fb_t_frames_f32"])
+    assert gl["fb_t_frames_f32"].size == 4000
+    for reader in (FBFileReader.ExtractFBFile, orc.extract_fb_file):
+        np.testing.assert_array_equal(reader(p)[0], gl["fb_t_matrix"])
+    hard = np.array([2.675, 1.005, 0.125, 0.375, 1234.565, 1000.5 / 100, 8.345, -2.675, 2.665, 1e-9, 0.0])
+    assert any(np.round(v, 2) != round(float(v), 2) for v in hard)            # the two rules do differ here
+    np.testing.assert_array_equal(FBFileReader.round_half_even_decimal(hard, 2), [round(float(v), 2) for v in hard])
+    rng = np.random.default_rng(0)
+    v = np.concatenate([rng.uniform(0, 4000, 20000), (rng.integers(0, 400000, 20000) + 0.5) / 100])
+    np.testing.assert_array_equal(FBFileReader.round_half_even_decimal(v, 2), [round(float(x), 2) for x in v])
+
+
+def test_label_rows_are_vectorised_and_tie_safe():
+    """slopes_and_pvalues against per-row lstsq + pearsonr (the reference's formulation), rounded as the CSV is,
+    on windows of two-decimal values where exact rounding ties are frequent."""
+    from scipy.stats import pearsonr
+    rng = np.random.default_rng(5)
+    windows = np.round(1500 + 400 * rng.standard_normal((3000, 1)) + 40 * rng.standard_normal((3000, 11)), 2)
+    steps = (800 + 160 * np.arange(3000)).astype(np.float64)
+    a, p = LabelDataGenerator.slopes_and_pvalues(windows, steps, 160)
+    ties = 0
+    for i in range(3000):
+        x = steps[i] + 160.0 * (np.arange(11) - 5)
+        (ar, br), _, _, _ = np.linalg.lstsq(np.vstack([x, np.ones(11)]).T, windows[i], rcond=None)
+        pr = pearsonr(windows[i], ar * x + br)[1]
+        assert round(ar, 5) == np.round(a[i], 5) and round(pr, 5) == np.round(p[i], 5), i
+        s5 = abs(ar) * 1e5
+        ties += abs(s5 - np.floor(s5) - 0.5) < 1e-6
+    assert ties > 20        # the fixture does exercise ties
+    assert LabelDataGenerator.phonemes_at([("aa", 0, 10), ("bb", 10, 20)], [0, 10, 11, 21]).tolist() == ["aa", "aa", "bb", "h#"]
+
+
 def test_phn_reader_matches_reference(gl, tmp_path):
     p = str(tmp_path / "x.PHN")
     open(p, "w").write(str(gl["phn_text"]))
