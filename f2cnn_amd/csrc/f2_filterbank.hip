@@ -20,6 +20,26 @@ namespace {
 
 constexpr int TB = 32;                 // samples per LDS tile
 constexpr int ROWS_PER_STORE = 64 / TB;
+// Wavefronts per workgroup. The waves of a workgroup are independent (own utterance/channel group, own LDS tile, no
+// workgroup barrier); they only share a workgroup so that the dispatcher places them one per SIMD of a CU. With
+// one-wave workgroups the 2000 waves of the benchmark batch land unevenly (some SIMDs run three, others one) and the
+// kernel takes as long as the fullest SIMD.
+#ifndef F2_K1_WAVES_F32
+#define F2_K1_WAVES_F32 4     // float32 hand-off tiles: 4 x 8.4 KB of LDS
+#endif
+#ifndef F2_K1_WAVES_F64
+#define F2_K1_WAVES_F64 2     // float64 output tiles: 2 x 16.9 KB (the store-bound variant gains nothing beyond two)
+#endif
+template <typename OutT>
+constexpr int waves_per_block() { return sizeof(OutT) == 4 ? F2_K1_WAVES_F32 : F2_K1_WAVES_F64; }
+
+// LDS hand-over between lanes of ONE wave: the wave's DS operations execute in order, so only the compiler has to be
+// kept from moving accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // OutT = double: the (C,N) float64 matrix of the reference. OutT = float: the same row layout but each row's
 // float32 samples sit at the START of that row's float64 slot (row r, sample t -> float index 2*r*N + t), the
@@ -27,17 +47,23 @@ constexpr int ROWS_PER_STORE = 64 / TB;
 // A2ZERO: the numerators have no z^-2 term (always true for make_erb_filters output): direct form II sections,
 // 13 float64 ops per sample-channel; otherwise the general transposed-direct-form-II recurrences (17 ops).
 template <typename WaveT, typename OutT, bool A2ZERO>
-__global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__ wave,
+__global__ __launch_bounds__(64 * waves_per_block<OutT>()) void k_erb_filterbank(const WaveT* __restrict__ wave,
                                                        const int64_t* __restrict__ offsets,
                                                        const double* __restrict__ coefs, int C,
-                                                       int groups, double* __restrict__ out,
+                                                       int groups, int units, double* __restrict__ out,
                                                        float* __restrict__ alt, const int64_t* __restrict__ alt_off) {
-    __shared__ OutT tile[64][TB + 1];
-    __shared__ double xs[TB];
+    constexpr int WPB = waves_per_block<OutT>();
+    __shared__ OutT tiles[WPB][64][TB + 1];
+    __shared__ double xss[WPB][TB];
 
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x / groups;
-    const int c0 = (blockIdx.x % groups) * 64;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int unit = blockIdx.x * WPB + wv;          // (utterance, group of 64 channels)
+    if (unit >= units) return;                       // whole wave: the waves of a workgroup never meet at a barrier
+    OutT (*tile)[TB + 1] = tiles[wv];
+    double* xs = xss[wv];
+    const int b = unit / groups;
+    const int c0 = (unit % groups) * 64;
     const int64_t off = offsets[b];
     const int64_t N = offsets[b + 1] - off;
     if (N <= 0) return;
@@ -84,7 +110,7 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
             const int64_t t = t0 + TB + lane;
             xnext = (lane < TB && t < N) ? w[t] : WaveT(0);
         }
-        __syncthreads();
+        wave_sync();
         // The four sections of one sample form a dependent chain (y1 -> y2 -> y3 -> y4). The block is written
         // out skewed -- step s runs section k on sample s-k+1 -- so that every step holds four independent
         // recurrences and the in-order VALU always has a ready float64 FMA.
@@ -160,7 +186,7 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
                 p3 = n3;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (fits32 && full_rows && t0 + TB <= N) {
             // whole tile inside the matrix: one 32-bit offset add per store, no checks
             uint32_t boff = (uint32_t)((((size_t)(c0 + srow) * (size_t)N) * ROWMUL + (size_t)(t0 + scol)) * sizeof(OutT));
@@ -184,19 +210,21 @@ __global__ __launch_bounds__(64) void k_erb_filterbank(const WaveT* __restrict__
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
 template <typename WaveT, typename OutT>
-void launch_fb(hipStream_t st, dim3 grid, bool a2zero, const void* wave, const int64_t* offsets, const double* coefs, int C,
+void launch_fb(hipStream_t st, int units, bool a2zero, const void* wave, const int64_t* offsets, const double* coefs, int C,
                int groups, double* out, float* alt = nullptr, const int64_t* alt_off = nullptr) {
+    constexpr int WPB = waves_per_block<OutT>();
+    const dim3 grid((unsigned)((units + WPB - 1) / WPB)), block(64 * WPB);
     if (a2zero)
-        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true>), grid, dim3(64), 0, st, (const WaveT*)wave, offsets, coefs, C,
-                           groups, out, alt, alt_off);
+        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true>), grid, block, 0, st, (const WaveT*)wave, offsets, coefs, C,
+                           groups, units, out, alt, alt_off);
     else
-        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, false>), grid, dim3(64), 0, st, (const WaveT*)wave, offsets, coefs,
-                           C, groups, out, alt, alt_off);
+        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, false>), grid, block, 0, st, (const WaveT*)wave, offsets, coefs,
+                           C, groups, units, out, alt, alt_off);
 }
 
 }  // namespace
@@ -209,19 +237,19 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
     const int64_t* alt_off = f32_out ? handoff->d_x32_off : nullptr;
     (void)h_offsets;
     const int groups = (C + 63) / 64;
-    const dim3 grid((unsigned)(B * groups));
+    const int units = B * groups;
     // the coefficient rows of this call are mirrored on the host by f2_upload_coefs
     bool a2zero = ctx->coefs_host.size() == (size_t)C * 10;
     for (int c = 0; a2zero && c < C; ++c) a2zero = ctx->coefs_host[(size_t)c * 10 + 5] == 0.0;
     F2_TRY(f2_prof_begin(ctx, F2_K_FILTERBANK));
     if (wave_dtype == F2_WAVE_I16 && !f32_out)
-        launch_fb<int16_t, double>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
+        launch_fb<int16_t, double>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
     else if (wave_dtype == F2_WAVE_I16)
-        launch_fb<int16_t, float>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off);
+        launch_fb<int16_t, float>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off);
     else if (!f32_out)
-        launch_fb<double, double>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
+        launch_fb<double, double>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
     else
-        launch_fb<double, float>(ctx->stream, grid, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off);
+        launch_fb<double, float>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_FILTERBANK));
     return F2_OK;
