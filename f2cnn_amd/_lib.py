@@ -14,7 +14,7 @@ import numpy as np
 from . import build as _build
 
 F2_OK, F2_ERR_INVALID, F2_ERR_HIP, F2_ERR_UNSUPPORTED, F2_ERR_NOMEM, F2_ERR_NONPOSITIVE = 0, -1, -2, -3, -4, -5
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_ASYNC = 0, 1, 2
 WAVE_I16, WAVE_F64 = 0, 1
 FFT_F32, FFT_F64 = 0, 1
 K_COUNT = 5
@@ -35,6 +35,8 @@ SIGNATURES = {
     "f2_dev_malloc": (_i, [_vp, C.c_size_t, _P(_vp)]),
     "f2_dev_free": (_i, [_vp, _vp]),
     "f2_dev_memset": (_i, [_vp, _vp, _i, C.c_size_t]),
+    "f2_host_alloc": (_i, [_vp, C.c_size_t, _P(_vp)]),
+    "f2_host_free": (_i, [_vp, _vp]),
     "f2_memcpy_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "f2_memcpy_d2h": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "f2_event_create": (_i, [_vp, _P(_vp)]),
@@ -121,6 +123,18 @@ def _ptr(a):
     return a  # int device pointer
 
 
+class _PinnedOwner:
+    def __init__(self, ctx, ptr):
+        self.ctx, self.ptr = ctx, ptr
+
+    def __del__(self):
+        try:
+            if self.ctx.handle and self.ptr:
+                self.ctx.lib.f2_host_free(self.ctx.handle, self.ptr)
+        except Exception:
+            pass
+
+
 class Context:
     """One f2_ctx: a device, a stream and its scratch memory. Not thread-safe (one host thread per context)."""
 
@@ -162,6 +176,14 @@ class Context:
 
     def free(self, dptr):
         self.check(self.lib.f2_dev_free(self.handle, dptr))
+
+    def host_alloc(self, nbytes):
+        """Page-locked host buffer of nbytes: a ctypes byte array (buffer protocol) that frees itself when collected."""
+        p = _vp()
+        self.check(self.lib.f2_host_alloc(self.handle, int(nbytes), C.byref(p)))
+        buf = (C.c_ubyte * int(nbytes)).from_address(p.value)
+        buf._f2_owner = _PinnedOwner(self, p.value)
+        return buf
 
     def memset(self, dptr, value, nbytes):
         self.check(self.lib.f2_dev_memset(self.handle, dptr, value, int(nbytes)))
@@ -259,6 +281,7 @@ class Context:
                                           _ptr(labels), mem_space))
 
 _default_ctx = {}
+_extra_ctx = {}
 
 
 def default_context(device=None):
@@ -269,3 +292,17 @@ def default_context(device=None):
     if ctx is None or ctx.handle is None:
         ctx = _default_ctx[device] = Context(device)
     return ctx
+
+
+def pipeline_contexts(n=2, device=None):
+    """n contexts (= n streams with their own staging memory) on one device, the first being the default context:
+    the file drivers alternate batches between them so that one batch's copies run beside the next one's kernels."""
+    first = default_context(device)
+    out = [first]
+    for i in range(1, n):
+        key = (first.device, i)
+        ctx = _extra_ctx.get(key)
+        if ctx is None or ctx.handle is None:
+            ctx = _extra_ctx[key] = Context(first.device)
+        out.append(ctx)
+    return out

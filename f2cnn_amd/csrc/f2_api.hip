@@ -67,7 +67,7 @@ int f2_prof_end(f2_ctx* ctx, int kernel_id) {
 
 extern "C" {
 
-int f2_version(void) { return 101; }   // 101: f2_eval_batch
+int f2_version(void) { return 102; }   // 101: f2_eval_batch; 102: f2_host_alloc, F2_MEM_HOST_ASYNC
 
 int f2_device_count(int* count) {
     if (!count) return f2_fail(nullptr, F2_ERR_INVALID, "count is NULL");
@@ -197,6 +197,28 @@ int f2_dev_free(f2_ctx* ctx, void* dptr) {
     return F2_OK;
 }
 
+int f2_host_alloc(f2_ctx* ctx, size_t bytes, void** hptr) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, hptr, F2_ERR_INVALID, "hptr is NULL");
+    *hptr = nullptr;
+    if (bytes == 0) return F2_OK;
+    F2_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        *hptr = nullptr;
+        return f2_fail(ctx, F2_ERR_NOMEM, "hipHostMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
+    }
+    return F2_OK;
+}
+
+int f2_host_free(f2_ctx* ctx, void* hptr) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    if (!hptr) return F2_OK;
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    F2_HIP(ctx, hipHostFree(hptr));
+    return F2_OK;
+}
+
 int f2_dev_memset(f2_ctx* ctx, void* dptr, int value, size_t bytes) {
     F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
     if (bytes == 0) return F2_OK;
@@ -301,7 +323,8 @@ const char* f2_prof_kernel_name(int kernel_id) {
 // ------------------------------------------------------------------------------------------------
 static int check_batch(f2_ctx* ctx, const int64_t* offsets, int B, int C, int mem_space) {
     F2_CHECK(ctx, B >= 0 && C >= 0, F2_ERR_INVALID, "negative batch (B=%d) or channel count (C=%d)", B, C);
-    F2_CHECK(ctx, mem_space == F2_MEM_HOST || mem_space == F2_MEM_DEVICE, F2_ERR_INVALID, "bad mem_space %d", mem_space);
+    F2_CHECK(ctx, mem_space == F2_MEM_HOST || mem_space == F2_MEM_DEVICE || mem_space == F2_MEM_HOST_ASYNC, F2_ERR_INVALID,
+             "bad mem_space %d", mem_space);
     F2_CHECK(ctx, offsets, F2_ERR_INVALID, "offsets is NULL");
     F2_CHECK(ctx, offsets[0] == 0, F2_ERR_INVALID, "offsets[0] must be 0");
     for (int b = 0; b < B; ++b)
@@ -383,7 +406,8 @@ int f2_erb_filterbank_batch(f2_ctx* ctx, const void* wave, int wave_dtype, const
     const void* d_wave = wave;
     double* d_gfb = gfb;
     const size_t out_bytes = sizeof(double) * (size_t)C * (size_t)total;
-    if (mem_space == F2_MEM_HOST) {
+    const bool staged = mem_space != F2_MEM_DEVICE;
+    if (staged) {
         F2_TRY(f2_reserve(ctx, ctx->stage_in, wave_elem(wave_dtype) * (size_t)total));
         F2_TRY(f2_reserve(ctx, ctx->stage_out, out_bytes));
         F2_HIP(ctx, hipMemcpyAsync(ctx->stage_in.ptr, wave, wave_elem(wave_dtype) * (size_t)total, hipMemcpyHostToDevice,
@@ -393,9 +417,9 @@ int f2_erb_filterbank_batch(f2_ctx* ctx, const void* wave, int wave_dtype, const
     }
     F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
                                 (const double*)ctx->coefs.ptr, B, C, d_gfb));
-    if (mem_space == F2_MEM_HOST) {
+    if (staged) {
         F2_HIP(ctx, hipMemcpyAsync(gfb, d_gfb, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (mem_space == F2_MEM_HOST) F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return F2_OK;
 }
@@ -414,16 +438,17 @@ int f2_envelope_batch(f2_ctx* ctx, const double* gfb, const int64_t* offsets, in
     const double* d_gfb = gfb;
     double* d_env = env;
     const size_t bytes = sizeof(double) * (size_t)C * (size_t)total;
-    if (mem_space == F2_MEM_HOST) {
+    const bool staged = mem_space != F2_MEM_DEVICE;
+    if (staged) {
         F2_TRY(f2_reserve(ctx, ctx->stage_out, bytes));
         F2_HIP(ctx, hipMemcpyAsync(ctx->stage_out.ptr, gfb, bytes, hipMemcpyHostToDevice, ctx->stream));
         d_gfb = d_env = (double*)ctx->stage_out.ptr;  // in place on the device
     }
     F2_TRY(f2_launch_envelope(ctx, d_gfb, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz,
                               fft_precision, d_env));
-    if (mem_space == F2_MEM_HOST) {
+    if (staged) {
         F2_HIP(ctx, hipMemcpyAsync(env, d_env, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (mem_space == F2_MEM_HOST) F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return F2_OK;
 }
@@ -446,7 +471,8 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
     const void* d_wave = wave;
     double* d_env = env;
     double* d_gfb = gfb_or_null;
-    if (mem_space == F2_MEM_HOST) {
+    const bool staged = mem_space != F2_MEM_DEVICE;
+    if (staged) {
         F2_TRY(f2_reserve(ctx, ctx->stage_in, wave_elem(wave_dtype) * (size_t)total));
         F2_TRY(f2_reserve(ctx, ctx->stage_out, bytes));
         if (gfb_or_null) F2_TRY(f2_reserve(ctx, ctx->stage_aux, bytes));
@@ -467,10 +493,10 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
                                 (const double*)ctx->coefs.ptr, B, C, k1_out, &handoff));
     F2_TRY(f2_launch_envelope(ctx, k1_out, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz,
                               fft_precision, d_env, &handoff));
-    if (mem_space == F2_MEM_HOST) {
+    if (staged) {
         F2_HIP(ctx, hipMemcpyAsync(env, d_env, bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (gfb_or_null) F2_HIP(ctx, hipMemcpyAsync(gfb_or_null, d_gfb, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (mem_space == F2_MEM_HOST) F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return F2_OK;
 }

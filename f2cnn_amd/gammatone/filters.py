@@ -85,13 +85,15 @@ def erb_filterbank(wave, coefs, ctx=None):
     return out
 
 
-def erb_filterbank_batch(waves, coefs, ctx=None, alloc=np.empty):
+def erb_filterbank_batch(waves, coefs, ctx=None, alloc=np.empty, wait=True):
     """List of waveforms (same dtype, any lengths) -> list of (C,N_b) matrices in one launch. `alloc(count, dtype=...)`
-    provides the output buffer (the file drivers pass a recycling pool)."""
+    provides the output buffer (the file drivers pass a pool of page-locked buffers). wait=False queues the copies
+    and the kernel on the context's stream (F2_MEM_HOST_ASYNC) and returns a function that waits for them and
+    returns the list."""
     ctx = ctx or _lib.default_context()
     coefs = np.ascontiguousarray(coefs, dtype=np.float64)
     if not len(waves):
-        return []
+        return [] if wait else (lambda: [])
     args = [_wave_args(w) for w in waves]
     dt = args[0][1] if all(a[1] == args[0][1] for a in args) else _lib.WAVE_F64
     dtype = np.int16 if dt == _lib.WAVE_I16 else np.float64
@@ -100,5 +102,9 @@ def erb_filterbank_batch(waves, coefs, ctx=None, alloc=np.empty):
     flat = np.concatenate([a[0].astype(dtype, copy=False) for a in args]) if offsets[-1] else np.zeros(0, dtype)
     Cn = coefs.shape[0]
     out = alloc(Cn * int(offsets[-1]), dtype=np.float64)
-    ctx.erb_filterbank_batch(flat, dt, offsets, coefs, len(args), Cn, out, _lib.MEM_HOST)
-    return [out[Cn * offsets[b]:Cn * offsets[b + 1]].reshape(Cn, -1) for b in range(len(args))]
+    ctx.erb_filterbank_batch(flat, dt, offsets, coefs, len(args), Cn, out, _lib.MEM_HOST if wait else _lib.MEM_HOST_ASYNC)
+
+    def finish(keep=(flat, offsets, coefs)):      # the host arrays of the queued copies live as long as this closure
+        ctx.synchronize()
+        return [out[Cn * offsets[b]:Cn * offsets[b + 1]].reshape(Cn, -1) for b in range(len(args))]
+    return finish() if wait else finish

@@ -13,29 +13,65 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy
 
 
-def run_batches(items, load, compute, save, batch=32, readers=4, writers=None, max_pending_writes=64):
-    """items -> load(item) [threads] -> compute(list of (item, loaded)) -> iterable of (item, result)
-    -> save(item, result) [threads]. Order of `compute` calls follows `items`; returns the number of items saved."""
+def _workers(kind):
+    """Thread counts for the box's CPU share (16 cores for one GPU): numpy.save to tmpfs reaches 25 GB/s with 8
+    threads and 43 GB/s with 16, reads into pooled buffers 41 / 61 GB/s (tools/io_probe.py)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    cores = max(2, min(cores, 16))
+    return max(2, cores - 6) if kind == "read" else max(4, cores - 4)
+
+
+def run_batches(items, load, compute, save, batch=32, readers=None, writers=None, max_pending_writes=64, plan=None,
+                depth=2):
+    """The file pipeline of the drivers:
+
+        plan(chunk) -> (batch_state, slots)   optional, main thread: e.g. read the headers, take one pooled buffer for
+                                              the batch and hand every item its slice of it
+        load(item[, slot])                    reader threads (NumPy / file I/O releases the GIL)
+        compute(loaded[, batch_state])        main thread; loaded = [(item, what load returned)]. Returns an iterable
+                                              of (item, result) or, for asynchronous device work, a zero-argument
+                                              callable that waits for the work and returns that iterable
+        save(item, result)                    writer threads
+
+    Up to `depth` computes stay un-collected (the drivers alternate two device contexts, so one batch's copies run
+    beside the next batch's kernels), the loads of the next batches run ahead on the reader threads, and the writes of
+    earlier batches drain on the writer threads. Order of `compute` calls follows `items`; returns the number of items
+    saved."""
     items = list(items)
     if not items:
         return 0
-    if writers is None:      # the .npy writes (16.4 MB per audio-second and stage) are the slowest stage
-        writers = max(4, min(8, (os.cpu_count() or 8) // 2))
+    readers = readers or _workers("read")
+    writers = writers or _workers("write")
     done = 0
     with ThreadPoolExecutor(readers) as rpool, ThreadPoolExecutor(writers) as wpool:
         def submit_loads(chunk):
-            return [(it, rpool.submit(load, it)) for it in chunk]
+            if plan is None:
+                return None, [(it, rpool.submit(load, it)) for it in chunk]
+            state, slots = plan(chunk)
+            return state, [(it, rpool.submit(load, it, slot)) for it, slot in zip(chunk, slots)]
         chunks = [items[s:s + batch] for s in range(0, len(items), batch)]
-        pending = submit_loads(chunks[0])
-        writes = []
-        for ci in range(len(chunks)):
-            loaded = [(it, f.result()) for it, f in pending]
-            pending = submit_loads(chunks[ci + 1]) if ci + 1 < len(chunks) else []
-            for it, res in compute(loaded):
-                writes.append(wpool.submit(save, it, res))
+        ahead = [submit_loads(chunks[0])]
+        if len(chunks) > 1:
+            ahead.append(submit_loads(chunks[1]))
+        in_flight, writes = [], []
+
+        def collect(res):
+            nonlocal done
+            for it, out in (res() if callable(res) else res):
+                writes.append(wpool.submit(save, it, out))
                 done += 1
             while len(writes) > max_pending_writes:     # bound the host memory held by queued results
                 writes.pop(0).result()
+        for ci in range(len(chunks)):
+            state, pending = ahead.pop(0)
+            loaded = [(it, f.result()) for it, f in pending]
+            if ci + 2 < len(chunks):
+                ahead.append(submit_loads(chunks[ci + 2]))
+            in_flight.append(compute(loaded) if plan is None else compute(loaded, state))
+            while len(in_flight) >= max(depth, 1):
+                collect(in_flight.pop(0))
+        while in_flight:
+            collect(in_flight.pop(0))
         for w in writes:
             w.result()
     return done
@@ -84,4 +120,39 @@ class ArrayPool:
         return arr
 
 
-host_pool = ArrayPool()
+def _pinned(nbytes):
+    """Page-locked buffer from the default device context (hipHostMalloc through f2_host_alloc): copies to and from
+    it can be queued asynchronously (F2_MEM_HOST_ASYNC)."""
+    from . import _lib
+    return _lib.default_context().host_alloc(nbytes)
+
+
+host_pool = ArrayPool(keep=16, alloc=_pinned)
+
+
+def npy_layout(path):
+    """(shape, data offset) of an NPY file holding a C-order '<f8' array, or None for anything else."""
+    with open(path, "rb") as f:
+        try:
+            version = numpy.lib.format.read_magic(f)
+            reader = numpy.lib.format.read_array_header_1_0 if version == (1, 0) else numpy.lib.format.read_array_header_2_0
+            shape, fortran, dtype = reader(f)
+        except ValueError:
+            return None
+        if fortran or dtype != numpy.dtype('<f8'):
+            return None
+        return shape, f.tell()
+
+
+def read_npy_into(path, offset, dest):
+    """Payload of an NPY file (see npy_layout) straight into `dest` (a writable contiguous array of the right size)."""
+    view = memoryview(dest).cast("B")
+    with open(path, "rb", buffering=0) as f:
+        f.seek(offset)
+        got = 0
+        while got < len(view):
+            n = f.readinto(view[got:])
+            if not n:
+                raise ValueError("{}: truncated NPY payload".format(path))
+            got += n
+    return dest

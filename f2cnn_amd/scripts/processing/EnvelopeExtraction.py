@@ -12,7 +12,7 @@ import time
 import numpy
 
 from ... import _lib
-from ...iopipe import host_pool, run_batches
+from ...iopipe import host_pool, npy_layout, read_npy_into, run_batches
 from ...runtime import shard_for_rank
 
 FFT_PRECISION = _lib.FFT_F64 if os.environ.get("F2CNN_FFT", "f32").lower() in ("f64", "double") else _lib.FFT_F32
@@ -91,28 +91,60 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16):
     mine = shard_for_rank(gfbFiles)
     progress = {"done": 0}
 
-    def load(name):
-        print("File:\t{}".format(name))
-        return numpy.load(name)
+    contexts = _lib.pipeline_contexts(2)     # alternate streams: one batch's copies beside the next one's kernels
+    turn = [0]
+    precision = FFT_PRECISION
 
-    def compute(loaded):
-        # one launch per distinct channel count (normally one)
-        by_c = {}
-        for i, (_, m) in enumerate(loaded):
-            by_c.setdefault(m.shape[0], []).append(i)
-        envs = [None] * len(loaded)
-        for idx in by_c.values():
-            for i, e in zip(idx, ExtractEnvelopesFromMatrices([loaded[i][1] for i in idx], LPF, CUTOFF,
-                                                                alloc=host_pool.empty)):
-                envs[i] = e
-        return [(loaded[i][0], envs[i]) for i in range(len(loaded))]
+    def plan(chunk):
+        """One pooled page-locked buffer per batch; every file is read straight into its (C, N_b) block of it."""
+        layouts = [npy_layout(name) for name in chunk]
+        plain = all(l is not None and len(l[0]) == 2 and l[0][0] == layouts[0][0][0] for l in layouts)
+        if not plain:                            # Fortran order, another dtype, mixed channel counts: general path
+            return None, [None] * len(chunk)
+        Cn = layouts[0][0][0]
+        offsets = numpy.zeros(len(chunk) + 1, dtype=numpy.int64)
+        offsets[1:] = numpy.cumsum([l[0][1] for l in layouts])
+        buf = host_pool.empty(Cn * int(offsets[-1]))
+        slots = [(buf[Cn * offsets[b]:Cn * offsets[b + 1]], layouts[b][1]) for b in range(len(chunk))]
+        return {"buf": buf, "offsets": offsets, "C": Cn}, slots
+
+    def load(name, slot):
+        print("File:\t{}".format(name))
+        if slot is None:
+            return numpy.load(name)
+        return read_npy_into(name, slot[1], slot[0])
+
+    def compute(loaded, state):
+        names = [n for n, _ in loaded]
+        if state is None:
+            # one launch per distinct channel count (normally one)
+            by_c = {}
+            for i, (_, m) in enumerate(loaded):
+                by_c.setdefault(m.shape[0], []).append(i)
+            envs = [None] * len(loaded)
+            for idx in by_c.values():
+                for i, e in zip(idx, ExtractEnvelopesFromMatrices([loaded[i][1] for i in idx], LPF, CUTOFF,
+                                                                    alloc=host_pool.empty)):
+                    envs[i] = e
+            return list(zip(names, envs))
+        ctx = contexts[turn[0] % len(contexts)]
+        turn[0] += 1
+        buf, offsets, Cn = state["buf"], state["offsets"], state["C"]
+        # in place on the host too: the envelopes come back over the filterbank rows they were computed from
+        ctx.envelope_batch(buf, offsets, len(names), Cn, bool(LPF), CUTOFF if LPF else 0.0, precision, buf,
+                           _lib.MEM_HOST_ASYNC)
+
+        def finish():
+            ctx.synchronize()
+            return [(names[b], buf[Cn * offsets[b]:Cn * offsets[b + 1]].reshape(Cn, -1)) for b in range(len(names))]
+        return finish
 
     def save(name, e):
         numpy.save(envelope_filename(name), e)
         progress["done"] += 1
         print("\t{:<50} done ! {}/{} Files.".format(envelope_filename(name), progress["done"], len(mine)))
 
-    run_batches(mine, load, compute, save, batch=batch_files)
+    run_batches(mine, load, compute, save, batch=batch_files, plan=plan)
     print("Extracted Envelopes from all files.")
     print('              Total time:', time.time() - TotalTime)
     print('')
@@ -137,7 +169,8 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True):
     _, coefs = filterbank_from_config()
     coefs = numpy.ascontiguousarray(coefs, dtype=numpy.float64)
     Cn = coefs.shape[0]
-    ctx = _lib.default_context()
+    contexts = _lib.pipeline_contexts(2)
+    turn = [0]
     mine = shard_for_rank(wavFiles)
     progress = {"done": 0}
 
@@ -145,6 +178,8 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True):
         return GetArrayFromWAV(name)[1]
 
     def compute(loaded):
+        ctx = contexts[turn[0] % len(contexts)]
+        turn[0] += 1
         args = [filters._wave_args(w) for _, w in loaded]
         dt = args[0][1] if all(a[1] == args[0][1] for a in args) else _lib.WAVE_F64
         dtype = numpy.int16 if dt == _lib.WAVE_I16 else numpy.float64
@@ -154,10 +189,14 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True):
         env = host_pool.empty(Cn * int(offsets[-1]))
         gfb = host_pool.empty(Cn * int(offsets[-1])) if keep_gfb else None
         ctx.filterbank_envelope_fused(flat, dt, offsets, coefs, len(args), Cn, bool(LPF), CUTOFF if LPF else 0.0,
-                                      FFT_PRECISION, env, gfb, _lib.MEM_HOST)
-        for b, (name, _) in enumerate(loaded):
-            sl = slice(Cn * offsets[b], Cn * offsets[b + 1])
-            yield name, (env[sl].reshape(Cn, -1), gfb[sl].reshape(Cn, -1) if keep_gfb else None)
+                                      FFT_PRECISION, env, gfb, _lib.MEM_HOST_ASYNC)
+
+        def finish(keep=(flat,)):
+            ctx.synchronize()
+            for b, (name, _) in enumerate(loaded):
+                sl = slice(Cn * offsets[b], Cn * offsets[b + 1])
+                yield name, (env[sl].reshape(Cn, -1), gfb[sl].reshape(Cn, -1) if keep_gfb else None)
+        return finish
 
     def save(name, res):
         env, gfb = res

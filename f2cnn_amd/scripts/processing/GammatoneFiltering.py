@@ -10,6 +10,7 @@ import time
 
 import numpy
 
+from ... import _lib
 from ...config import F2Config
 from ...gammatone import filters
 from ...iopipe import host_pool, run_batches
@@ -55,7 +56,7 @@ def filterbank_from_config(cfg=None):
     return cf, filters.make_erb_filters(cfg.framerate, cf)
 
 
-def FilterAllOrganisedFiles(batch_files=32):
+def FilterAllOrganisedFiles(batch_files=16):
     """`prepare filter`: every resources/f2cnn/*/*.WAV -> .GFB.npy (reference :93-128)."""
     TotalTime = time.time()
     wavFiles = sorted(glob.glob(os.path.join("resources", "f2cnn", "*", "*.WAV")))
@@ -73,9 +74,17 @@ def FilterAllOrganisedFiles(batch_files=32):
         print("Filtering:\t{}".format(name))
         return GetArrayFromWAV(name)[1]
 
+    # batches alternate between two device contexts (streams): the device-to-host copy of one batch runs beside the
+    # host-to-device copy and the kernel of the next, while writer threads save the batch before
+    contexts = _lib.pipeline_contexts(2)
+    turn = [0]
+
     def compute(loaded):
+        ctx = contexts[turn[0] % len(contexts)]
+        turn[0] += 1
         names = [n for n, _ in loaded]
-        return zip(names, filters.erb_filterbank_batch([w for _, w in loaded], coefs, alloc=host_pool.empty))
+        finish = filters.erb_filterbank_batch([w for _, w in loaded], coefs, ctx=ctx, alloc=host_pool.empty, wait=False)
+        return lambda: zip(names, finish())
 
     def save(name, m):
         gfb = os.path.splitext(name)[0] + '.GFB'

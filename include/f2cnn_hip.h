@@ -41,14 +41,19 @@ typedef enum {
     F2_ERR_NONPOSITIVE = -5   /* normalizeInput met a value <= 0 (reference: ValueError)       */
 } f2_status;
 
-enum { F2_MEM_HOST = 0, F2_MEM_DEVICE = 1 };
+/* F2_MEM_HOST_ASYNC: host pointers like F2_MEM_HOST, but the call returns as soon as the copies and kernels are
+ * queued on the context's stream; the host buffers must stay valid (and should be page-locked: f2_host_alloc, so
+ * that the copies really are asynchronous) until f2_ctx_synchronize() returns. The file drivers use it with two
+ * contexts so that batch k's device-to-host copy runs beside batch k+1's host-to-device copy and kernels.
+ * Accepted by f2_erb_filterbank_batch, f2_envelope_batch and f2_filterbank_envelope_fused. */
+enum { F2_MEM_HOST = 0, F2_MEM_DEVICE = 1, F2_MEM_HOST_ASYNC = 2 };
 enum { F2_WAVE_I16 = 0, F2_WAVE_F64 = 1 };
 /* arithmetic of the Hilbert FFT: F2_FFT_F32 (default; 3.6e-7 max-norm error) or
  * F2_FFT_F64 (reference-grade, slower). The IIR recurrences are float64 in both. */
 enum { F2_FFT_F32 = 0, F2_FFT_F64 = 1 };
 
 /* ---- library / context -------------------------------------------------------------------- */
-int f2_version(void);   /* 100 * major + minor; 101 added f2_eval_batch */
+int f2_version(void);   /* 100 * major + minor; 101 added f2_eval_batch, 102 f2_host_alloc + F2_MEM_HOST_ASYNC */
 int f2_device_count(int* count);
 int f2_ctx_create(int device, f2_ctx** ctx);
 int f2_ctx_destroy(f2_ctx* ctx);
@@ -63,6 +68,10 @@ const char* f2_last_error(f2_ctx* ctx);
 int f2_dev_malloc(f2_ctx* ctx, size_t bytes, void** dptr);
 int f2_dev_free(f2_ctx* ctx, void* dptr);
 int f2_dev_memset(f2_ctx* ctx, void* dptr, int value, size_t bytes);
+/* page-locked host memory for the staging buffers of F2_MEM_HOST / F2_MEM_HOST_ASYNC calls (the reference's
+ * numpy.save / numpy.load buffers, GammatoneFiltering.py:61-62, EnvelopeExtraction.py:80,94-95) */
+int f2_host_alloc(f2_ctx* ctx, size_t bytes, void** hptr);
+int f2_host_free(f2_ctx* ctx, void* hptr);
 int f2_memcpy_h2d(f2_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int f2_memcpy_d2h(f2_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int f2_event_create(f2_ctx* ctx, void** event);

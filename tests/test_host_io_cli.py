@@ -216,6 +216,52 @@ def test_iopipe_order_and_completeness():
     assert run_batches([], load, compute, save) == 0
 
 
+def test_run_batches_with_plans_and_deferred_computes(tmp_path):
+    """plan -> per-item slots, computes that finish later (the asynchronous device batches), ordered collection."""
+    from f2cnn_amd.iopipe import npy_layout, read_npy_into, run_batches
+    mats = [np.random.default_rng(i).random((3, 40 + i)) for i in range(11)]
+    for i, m in enumerate(mats):
+        np.save(tmp_path / f"m{i}.npy", m)
+    np.save(tmp_path / "fortran.npy", np.asfortranarray(mats[0]))
+    np.save(tmp_path / "f4.npy", mats[0].astype(np.float32))
+    assert npy_layout(tmp_path / "fortran.npy") is None and npy_layout(tmp_path / "f4.npy") is None
+    shape, off = npy_layout(tmp_path / "m3.npy")
+    assert shape == (3, 43) and off % 64 == 0
+    events, saved = [], {}
+
+    def plan(chunk):
+        lay = [npy_layout(tmp_path / f"m{i}.npy") for i in chunk]
+        buf = np.empty(sum(l[0][0] * l[0][1] for l in lay))
+        cuts = np.cumsum([0] + [l[0][0] * l[0][1] for l in lay])
+        return {"buf": buf, "cuts": cuts}, [(buf[a:b], l[1]) for a, b, l in zip(cuts[:-1], cuts[1:], lay)]
+
+    def load(i, slot):
+        return read_npy_into(tmp_path / f"m{i}.npy", slot[1], slot[0])
+
+    def compute(loaded, state):
+        ids = [i for i, _ in loaded]
+        events.append(("submit", ids[0]))
+        for (i, got), a, b in zip(loaded, state["cuts"][:-1], state["cuts"][1:]):
+            assert got.base is state["buf"] or got is state["buf"]            # read straight into the batch buffer
+            np.testing.assert_array_equal(state["buf"][a:b], mats[i].reshape(-1))
+
+        def finish():
+            events.append(("finish", ids[0]))
+            return [(i, state["buf"][a:b].copy() * 2) for i, a, b in zip(ids, state["cuts"][:-1], state["cuts"][1:])]
+        return finish
+
+    def save(i, v):
+        saved[i] = v
+
+    assert run_batches(range(11), load, compute, save, batch=4, readers=3, writers=2, plan=plan, depth=2) == 11
+    # two batches are queued before the first is collected; collection keeps submission order
+    assert events == [("submit", 0), ("submit", 4), ("finish", 0), ("submit", 8), ("finish", 4), ("finish", 8)]
+    for i, m in enumerate(mats):
+        np.testing.assert_array_equal(saved[i], m.reshape(-1) * 2)
+    with pytest.raises(ValueError):
+        read_npy_into(tmp_path / "m0.npy", off, np.empty(10 ** 4))            # more than the file holds
+
+
 def test_array_pool_recycles_only_unreferenced_owners():
     import gc
     from f2cnn_amd.iopipe import ArrayPool
