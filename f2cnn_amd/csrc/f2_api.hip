@@ -146,6 +146,8 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     for (f2_scratch& s : ctx->tw_split)
         if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->work3.ptr) (void)hipFree(ctx->work3.ptr);
+    if (ctx->k1_states.ptr) (void)hipFree(ctx->k1_states.ptr);
+    if (ctx->k1_mtab.ptr) (void)hipFree(ctx->k1_mtab.ptr);
     if (ctx->handoff.ptr) (void)hipFree(ctx->handoff.ptr);
     if (ctx->handoff_off.ptr) (void)hipFree(ctx->handoff_off.ptr);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);

@@ -14,6 +14,9 @@
 //
 // Bound: the float64 FMA pipe (13 ops per sample-channel; 17 in the general form); HBM traffic is 8*C*N bytes
 // written per utterance (4*C*N as the float32 hand-off to K2) + 2*N read.
+#include <algorithm>
+#include <cstdlib>
+
 #include "f2_internal.h"
 
 namespace {
@@ -30,8 +33,9 @@ constexpr int ROWS_PER_STORE = 64 / TB;
 #ifndef F2_K1_WAVES_F64
 #define F2_K1_WAVES_F64 2     // float64 output tiles: 2 x 16.9 KB (the store-bound variant gains nothing beyond two)
 #endif
-template <typename OutT>
-constexpr int waves_per_block() { return sizeof(OutT) == 4 ? F2_K1_WAVES_F32 : F2_K1_WAVES_F64; }
+// (MODE 2 of the time-split path keeps a 32 KB matrix table per wave in LDS: two waves per workgroup)
+template <typename OutT, int MODE = 0>
+constexpr int waves_per_block() { return MODE == 2 ? 2 : sizeof(OutT) == 4 ? F2_K1_WAVES_F32 : F2_K1_WAVES_F64; }
 
 // LDS hand-over between lanes of ONE wave: the wave's DS operations execute in order, so only the compiler has to be
 // kept from moving accesses across this point.
@@ -46,27 +50,52 @@ __device__ __forceinline__ void wave_sync() {
 // hand-off format to the float32-FFT envelope kernel, which then overwrites the slot with float64 envelopes.
 // A2ZERO: the numerators have no z^-2 term (always true for make_erb_filters output): direct form II sections,
 // 13 float64 ops per sample-channel; otherwise the general transposed-direct-form-II recurrences (17 ops).
-template <typename WaveT, typename OutT, bool A2ZERO>
-__global__ __launch_bounds__(64 * waves_per_block<OutT>()) void k_erb_filterbank(const WaveT* __restrict__ wave,
+// Time-split execution for small batches (MODE 1 / 2; MODE 0 is the plain kernel). A wave that walks a whole
+// utterance needs ~47 ns per sample whatever the batch size, so B utterances never take less than N * 47 ns and a
+// small batch leaves the chip idle. The recurrences are linear: with S the eight state words entering a segment of
+// L samples and E the state a run from ZERO state leaves at its end, the true state at the end is  M S + E,
+// M = T^L (T = the 8 x 8 zero-input transition of one sample; per channel, from the host in long double). So
+//   pass 1 (MODE 1): every (unit, segment) wave runs its segment from zero state, stores nothing but E;
+//   pass 2 (MODE 2): every (unit, segment) wave first chains S_j = M S_(j-1) + E_(j-1) over the segments before
+//                    its own (at most K-1 steps of 64 FMAs, M in LDS), then runs its segment from S_j and stores.
+// Twice the arithmetic, 1/K of the latency (+ the chain); the results differ from the serial run by float64 rounding.
+struct SplitArgs {
+    int K;                  // segments per utterance
+    int L;                  // samples per segment (multiple of TB)
+    double* states;         // [unit][K][8][64 lanes]: E of every segment
+    const double* mtab;     // [C][8][8]: M = T^L, row major
+};
+
+template <typename WaveT, typename OutT, bool A2ZERO, int MODE>
+__global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_filterbank(const WaveT* __restrict__ wave,
                                                        const int64_t* __restrict__ offsets,
                                                        const double* __restrict__ coefs, int C,
                                                        int groups, int units, double* __restrict__ out,
-                                                       float* __restrict__ alt, const int64_t* __restrict__ alt_off) {
-    constexpr int WPB = waves_per_block<OutT>();
+                                                       float* __restrict__ alt, const int64_t* __restrict__ alt_off,
+                                                       SplitArgs sp) {
+    static_assert(MODE == 0 || A2ZERO, "the time-split path uses the direct-form-II state words");
+    constexpr int WPB = waves_per_block<OutT, MODE>();
     __shared__ OutT tiles[WPB][64][TB + 1];
     __shared__ double xss[WPB][TB];
+    __shared__ double msh[MODE == 2 ? WPB : 1][MODE == 2 ? 64 : 1][64];   // M of this wave's channels, [entry][lane]
 
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int unit = blockIdx.x * WPB + wv;          // (utterance, group of 64 channels)
+    const int wid = threadIdx.x >> 6;
+    const int useg = blockIdx.x * WPB + wid;          // (utterance, group of 64 channels[, segment])
+    const int K = MODE == 0 ? 1 : sp.K;
+    const int unit = MODE == 0 ? useg : useg / K;
+    const int seg = MODE == 0 ? 0 : useg - unit * K;
     if (unit >= units) return;                       // whole wave: the waves of a workgroup never meet at a barrier
-    OutT (*tile)[TB + 1] = tiles[wv];
-    double* xs = xss[wv];
+    OutT (*tile)[TB + 1] = tiles[wid];
+    double* xs = xss[wid];
     const int b = unit / groups;
     const int c0 = (unit % groups) * 64;
     const int64_t off = offsets[b];
     const int64_t N = offsets[b + 1] - off;
     if (N <= 0) return;
+    const int64_t t_begin = MODE == 0 ? 0 : (int64_t)seg * sp.L;
+    const int64_t t_end = MODE == 0 ? N : min(N, t_begin + sp.L);
+    if (t_begin >= N) return;
 
     const int c = min(c0 + lane, C - 1);  // idle lanes shadow the last channel; their rows are never stored
     const double* k = coefs + (size_t)c * 10;
@@ -82,6 +111,30 @@ __global__ __launch_bounds__(64 * waves_per_block<OutT>()) void k_erb_filterbank
     const double scale = (b0 * b0) * (b0 * b0) * inv_gain;
 
     double z10 = 0, z11 = 0, z20 = 0, z21 = 0, z30 = 0, z31 = 0, z40 = 0, z41 = 0;
+    if constexpr (MODE == 2) {
+        if (seg > 0) {
+            // true state entering this segment: S_j = M S_(j-1) + E_(j-1), S_0 = 0
+            const double* mrow = sp.mtab + (size_t)c * 64;
+#pragma unroll 8
+            for (int i = 0; i < 64; ++i) msh[wid][i][lane] = mrow[i];
+            wave_sync();
+            double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const double* e = sp.states + ((size_t)unit * K) * 8 * 64 + lane;
+            for (int j = 0; j < seg; ++j, e += 8 * 64) {
+                double Sn[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    double acc = e[r * 64];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = fma(msh[wid][r * 8 + q][lane], S[q], acc);
+                    Sn[r] = acc;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) S[r] = Sn[r];
+            }
+            z10 = S[0], z11 = S[1], z20 = S[2], z21 = S[3], z30 = S[4], z31 = S[5], z40 = S[6], z41 = S[7];
+        }
+    }
 
     const WaveT* w = wave + off;
     // row pitch in OutT elements = ROWMUL * N: float rows sit at the start of their float64 slot, unless this utterance
@@ -103,8 +156,8 @@ __global__ __launch_bounds__(64 * waves_per_block<OutT>()) void k_erb_filterbank
 
     // The input block is fetched one block ahead: vmcnt retires in issue order (stores included), so a load
     // issued after a block's 32 row stores would make the wave wait for those stores every block.
-    WaveT xnext = (lane < TB && lane < N) ? w[lane] : WaveT(0);
-    for (int64_t t0 = 0; t0 < N; t0 += TB) {
+    WaveT xnext = (lane < TB && t_begin + lane < N) ? w[t_begin + lane] : WaveT(0);
+    for (int64_t t0 = t_begin; t0 < t_end; t0 += TB) {
         if (lane < TB) xs[lane] = (double)xnext;
         {
             const int64_t t = t0 + TB + lane;
@@ -143,7 +196,7 @@ __global__ __launch_bounds__(64 * waves_per_block<OutT>()) void k_erb_filterbank
                 }
                 if (s2 >= 3) {
                     const double wv = fma(-a1, z40, fma(-a2, z41, p3));
-                    tile[lane][s2 - 3] = (OutT)(fma(c4, z40, wv) * scale);
+                    if constexpr (MODE != 1) tile[lane][s2 - 3] = (OutT)(fma(c4, z40, wv) * scale);
                     z41 = z40;
                     z40 = wv;
                 }
@@ -186,6 +239,10 @@ __global__ __launch_bounds__(64 * waves_per_block<OutT>()) void k_erb_filterbank
                 p3 = n3;
             }
         }
+        if constexpr (MODE == 1) {                    // pass 1 of the time-split path keeps only the state
+            wave_sync();
+            continue;
+        }
         wave_sync();
         if (fits32 && full_rows && t0 + TB <= N) {
             // whole tile inside the matrix: one 32-bit offset add per store, no checks
@@ -212,19 +269,90 @@ __global__ __launch_bounds__(64 * waves_per_block<OutT>()) void k_erb_filterbank
         }
         wave_sync();
     }
+    if constexpr (MODE == 1) {
+        double* e = sp.states + ((size_t)unit * K + seg) * 8 * 64 + lane;
+        e[0] = z10, e[64] = z11, e[128] = z20, e[192] = z21, e[256] = z30, e[320] = z31, e[384] = z40, e[448] = z41;
+    }
 }
 
 template <typename WaveT, typename OutT>
 void launch_fb(hipStream_t st, int units, bool a2zero, const void* wave, const int64_t* offsets, const double* coefs, int C,
-               int groups, double* out, float* alt = nullptr, const int64_t* alt_off = nullptr) {
+               int groups, double* out, float* alt, const int64_t* alt_off, const SplitArgs& sp) {
     constexpr int WPB = waves_per_block<OutT>();
-    const dim3 grid((unsigned)((units + WPB - 1) / WPB)), block(64 * WPB);
+    const dim3 block(64 * WPB);
+    if (sp.K > 1) {
+        // time-split path (a2zero only): pass 1 leaves the zero-state end states, pass 2 chains them and stores
+        constexpr int WPB2 = waves_per_block<OutT, 2>();
+        const size_t waves = (size_t)units * sp.K;
+        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true, 1>), dim3((unsigned)((waves + WPB - 1) / WPB)), block, 0, st,
+                           (const WaveT*)wave, offsets, coefs, C, groups, units, out, alt, alt_off, sp);
+        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true, 2>), dim3((unsigned)((waves + WPB2 - 1) / WPB2)), dim3(64 * WPB2),
+                           0, st, (const WaveT*)wave, offsets, coefs, C, groups, units, out, alt, alt_off, sp);
+        return;
+    }
+    const dim3 grid((unsigned)((units + WPB - 1) / WPB));
     if (a2zero)
-        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true>), grid, block, 0, st, (const WaveT*)wave, offsets, coefs, C,
-                           groups, units, out, alt, alt_off);
+        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true, 0>), grid, block, 0, st, (const WaveT*)wave, offsets, coefs, C,
+                           groups, units, out, alt, alt_off, sp);
     else
-        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, false>), grid, block, 0, st, (const WaveT*)wave, offsets, coefs,
-                           C, groups, units, out, alt, alt_off);
+        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, false, 0>), grid, block, 0, st, (const WaveT*)wave, offsets, coefs,
+                           C, groups, units, out, alt, alt_off, sp);
+}
+
+// M = T^L per channel for the time-split path. T is the zero-input transition of the eight state words
+// (w1[-1], w1[-2], ..., w4[-1], w4[-2]) over one sample of the direct-form-II cascade the kernel runs:
+//   w_k = in_k - a1 w_k[-1] - a2 w_k[-2],  out_k = w_k + c_k w_k[-1],  in_(k+1) = out_k,  in_1 = 0
+void transition_power(const double* coef_row, int L, double* M) {
+    typedef long double ld;
+    const ld b0inv = 1.0L / (ld)coef_row[6];
+    const ld a1 = (ld)coef_row[7] * b0inv, a2 = (ld)coef_row[8] * b0inv;
+    const ld ck[4] = {(ld)coef_row[1] / (ld)coef_row[0], (ld)coef_row[2] / (ld)coef_row[0], (ld)coef_row[3] / (ld)coef_row[0],
+                      (ld)coef_row[4] / (ld)coef_row[0]};
+    ld T[8][8], R[8][8], X[8][8];
+    for (int col = 0; col < 8; ++col) {
+        ld v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nv[8];
+        v[col] = 1;
+        ld in = 0;
+        for (int k = 0; k < 4; ++k) {
+            const ld w = in - a1 * v[2 * k] - a2 * v[2 * k + 1];
+            in = w + ck[k] * v[2 * k];
+            nv[2 * k] = w;
+            nv[2 * k + 1] = v[2 * k];
+        }
+        for (int r = 0; r < 8; ++r) T[r][col] = nv[r];
+    }
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) R[r][c] = r == c ? 1 : 0;
+    for (int bits = L; bits; bits >>= 1) {            // R = T^L by binary powering
+        if (bits & 1) {
+            for (int r = 0; r < 8; ++r)
+                for (int c = 0; c < 8; ++c) {
+                    ld acc = 0;
+                    for (int q = 0; q < 8; ++q) acc += R[r][q] * T[q][c];
+                    X[r][c] = acc;
+                }
+            memcpy(R, X, sizeof(R));
+        }
+        for (int r = 0; r < 8; ++r)
+            for (int c = 0; c < 8; ++c) {
+                ld acc = 0;
+                for (int q = 0; q < 8; ++q) acc += T[r][q] * T[q][c];
+                X[r][c] = acc;
+            }
+        memcpy(T, X, sizeof(T));
+    }
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) M[r * 8 + c] = (double)R[r][c];
+}
+
+// Segments per utterance for this batch: 1 (plain kernel) unless the batch is too small to fill the chip.
+int split_segments(int units, int64_t nmax) {
+    const char* env = getenv("F2CNN_K1_SPLIT");            // 0 = never, K >= 2 = force K segments
+    const int forced = env ? atoi(env) : -1;
+    if (forced == 0 || nmax < 2 * TB) return 1;
+    int K = forced >= 2 ? forced : (units <= 256 ? std::min(32, 2048 / std::max(units, 1)) : 1);
+    K = (int)std::min<int64_t>(K, (nmax + 8 * TB - 1) / (8 * TB));   // at least 256 samples per segment
+    return std::max(K, 1);
 }
 
 }  // namespace
@@ -235,21 +363,46 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
     const bool f32_out = handoff && handoff->f32;
     float* alt = f32_out ? handoff->d_x32 : nullptr;
     const int64_t* alt_off = f32_out ? handoff->d_x32_off : nullptr;
-    (void)h_offsets;
     const int groups = (C + 63) / 64;
     const int units = B * groups;
     // the coefficient rows of this call are mirrored on the host by f2_upload_coefs
     bool a2zero = ctx->coefs_host.size() == (size_t)C * 10;
     for (int c = 0; a2zero && c < C; ++c) a2zero = ctx->coefs_host[(size_t)c * 10 + 5] == 0.0;
+    SplitArgs sp = {1, 0, nullptr, nullptr};
+    if (a2zero) {
+        int64_t nmax = 0;
+        for (int b = 0; b < B; ++b) nmax = std::max(nmax, h_offsets[b + 1] - h_offsets[b]);
+        const int K = split_segments(units, nmax);
+        if (K > 1) {
+            sp.L = (int)(((nmax + K - 1) / K + TB - 1) / TB * TB);
+            sp.K = (int)((nmax + sp.L - 1) / sp.L);
+        }
+        if (sp.K > 1) {
+            if (ctx->k1_mtab_L != sp.L || ctx->k1_mtab_coefs != ctx->coefs_host) {
+                std::vector<double> m((size_t)C * 64);
+                for (int c = 0; c < C; ++c) transition_power(&ctx->coefs_host[(size_t)c * 10], sp.L, &m[(size_t)c * 64]);
+                F2_TRY(f2_reserve(ctx, ctx->k1_mtab, sizeof(double) * m.size()));
+                F2_HIP(ctx, hipMemcpyAsync(ctx->k1_mtab.ptr, m.data(), sizeof(double) * m.size(), hipMemcpyHostToDevice, ctx->stream));
+                F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `m` is a local
+                ctx->k1_mtab_L = sp.L;
+                ctx->k1_mtab_coefs = ctx->coefs_host;
+            }
+            F2_TRY(f2_reserve(ctx, ctx->k1_states, sizeof(double) * 8 * 64 * (size_t)units * sp.K));
+            sp.states = (double*)ctx->k1_states.ptr;
+            sp.mtab = (const double*)ctx->k1_mtab.ptr;
+        } else {
+            sp.K = 1;
+        }
+    }
     F2_TRY(f2_prof_begin(ctx, F2_K_FILTERBANK));
     if (wave_dtype == F2_WAVE_I16 && !f32_out)
-        launch_fb<int16_t, double>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
+        launch_fb<int16_t, double>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, nullptr, nullptr, sp);
     else if (wave_dtype == F2_WAVE_I16)
-        launch_fb<int16_t, float>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off);
+        launch_fb<int16_t, float>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off, sp);
     else if (!f32_out)
-        launch_fb<double, double>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb);
+        launch_fb<double, double>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, nullptr, nullptr, sp);
     else
-        launch_fb<double, float>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off);
+        launch_fb<double, float>(ctx->stream, units, a2zero, d_wave, d_offsets, d_coefs, C, groups, d_gfb, alt, alt_off, sp);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_FILTERBANK));
     return F2_OK;

@@ -37,6 +37,9 @@ struct f2_ctx {
     f2_scratch tw_split[24];      // tables of the four-step transform (f2_envelope_split.hip), by log2 H
     f2_scratch work3;             // utterance lists of the four-step launches
     f2_scratch handoff, handoff_off;   // float32 hand-off of long rows (f2_plan_handoff)
+    f2_scratch k1_states, k1_mtab;     // time-split filterbank (small batches): segment end states, T^L per channel
+    int k1_mtab_L = 0;                 // segment length k1_mtab was built for ...
+    std::vector<double> k1_mtab_coefs; // ... and the coefficient rows
     std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
     std::vector<double> coefs_host;     // what ctx->coefs currently holds
     bool prof_on = false;

@@ -3,6 +3,7 @@
 import csv
 import os
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy
 
@@ -35,43 +36,46 @@ def gather_windows(envelopes, centers, radius, step, normalize=False, ctx=None):
 
 
 def GenerateInputData(labelFile=None, inputFile=None, LPF=False, CUTOFF=100):
-    """`prepare input` (reference :28-93): entries ordered by sorted(file) then CSV order within a file."""
-    TotalTime = time.time()
+    """`prepare input` (reference :28-93): one (2*RADIUS+1, C) window per labelled timepoint -> input_data*.npy.
+
+    Row order is part of the file format: envelope files in sorted path order, timepoints of a file in CSV order
+    (`cnn train` pairs row i of this matrix with CSV line i, which holds when the CSV itself is path-sorted, as
+    `prepare label` writes it). The rows of every file are therefore known before anything is read: each file's block
+    is gathered by K3 straight into its place, while reader threads fetch the next envelope files."""
+    started = time.time()
     if not os.path.isdir("trainingData"):
         print("LABEL GENERATION SHOULD BE DONE PRIOR TO INPUT...")
         exit(-1)
-    csvFilename = labelFile or os.path.join("trainingData", "label_data.csv")
-    filesAndTimepointsDict = GetListOfEnvelopeFilesAndTimepoints(csvFilename)
-    print("\n###############################\nGenerating Input Data from files with '{}'.".format(csvFilename))
-    if LPF:
-        print("Using Low Pass Filtering with a cutoff at {}Hz".format(CUTOFF))
-    else:
-        print("Not using Low Pass Filtering")
-    if not filesAndTimepointsDict:
+    label_csv = labelFile or os.path.join("trainingData", "label_data.csv")
+    per_file = GetListOfEnvelopeFilesAndTimepoints(label_csv)
+    print("\n###############################\nGenerating Input Data from files with '{}'.".format(label_csv))
+    print("Using Low Pass Filtering with a cutoff at {}Hz".format(CUTOFF) if LPF else "Not using Low Pass Filtering")
+    if not per_file:
         print("NO ENV1.npy FILES FOUND, PLEASE GENERATE ENVELOPES")
         exit(-1)
-    files = sorted(filesAndTimepointsDict.keys())
-    totalTimePoints = sum(len(v) for v in filesAndTimepointsDict.values())
-    print(len(files), "files found along with their", totalTimePoints, "entry timepoints.")
+    order = sorted(per_file)
+    first_row = numpy.concatenate([[0], numpy.cumsum([len(per_file[name]) for name in order])])
+    print(len(order), "files found along with their", int(first_row[-1]), "entry timepoints.")
     cfg = F2Config()
-    inputData = numpy.zeros((totalTimePoints, cfg.dots_per_input, cfg.nchannels), dtype=numpy.float32)
-    print("Output shape:", inputData.shape)
-    currentEntry = 0
-    for currentFileIndex, file in enumerate(files):
-        timepoints = filesAndTimepointsDict[file]
-        path = os.path.join('resources', 'f2cnn', file)
-        print("Reading:\t{}".format(path))
-        envelopes = numpy.load(path)
-        block = gather_windows(envelopes, timepoints, cfg.radius, cfg.step)
-        inputData[currentEntry:currentEntry + len(timepoints)] = block
-        currentEntry += len(timepoints)
-        print("\t\t{:<50} done !  {}/{} Files".format(path, currentFileIndex + 1, len(files)))
-    print('Generated Input Matrix of shape {}.'.format(inputData.shape))
-    savePath = inputFile or os.path.join(
-        'trainingData', 'input_data_LPF{}.npy'.format(CUTOFF) if LPF else 'input_data_NOLPF.npy')
-    print("Saving as {}...".format(savePath))
-    os.makedirs(os.path.split(savePath)[0] or '.', exist_ok=True)
-    numpy.save(savePath, inputData)
-    numpy.save(os.path.join('trainingData', 'last_input_data.npy'), inputData)
-    print('                Total time:', time.time() - TotalTime)
+    windows = numpy.empty((int(first_row[-1]), cfg.dots_per_input, cfg.nchannels), dtype=numpy.float32)
+    print("Output shape:", windows.shape)
+
+    def fetch(name):
+        return numpy.load(os.path.join('resources', 'f2cnn', name))
+    with ThreadPoolExecutor(4) as readers:
+        ahead = [readers.submit(fetch, name) for name in order[:3]]
+        for k, name in enumerate(order):
+            envelopes = ahead.pop(0).result()
+            if k + 3 < len(order):
+                ahead.append(readers.submit(fetch, order[k + 3]))
+            windows[first_row[k]:first_row[k + 1]] = gather_windows(envelopes, per_file[name], cfg.radius, cfg.step)
+            print("\t\t{:<50} done !  {}/{} Files".format(os.path.join('resources', 'f2cnn', name), k + 1, len(order)))
+    print('Generated Input Matrix of shape {}.'.format(windows.shape))
+    target = inputFile or os.path.join('trainingData',
+                                       'input_data_LPF{}.npy'.format(CUTOFF) if LPF else 'input_data_NOLPF.npy')
+    print("Saving as {}...".format(target))
+    os.makedirs(os.path.dirname(target) or '.', exist_ok=True)
+    numpy.save(target, windows)
+    numpy.save(os.path.join('trainingData', 'last_input_data.npy'), windows)    # the reference's backup copy (:90)
+    print('                Total time:', time.time() - started)
     print('')

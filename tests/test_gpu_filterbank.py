@@ -1,4 +1,6 @@
 """K1 parity on the GPU, through the C ABI: HIP filterbank vs the oracle and the reference's golden vectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -69,3 +71,40 @@ def test_bad_arguments():
         ctx.erb_filterbank_batch(np.zeros(4, np.int16), 0, np.array([1, 4], np.int64), co, 1, 4, np.zeros(16), 0)
     with pytest.raises(ValueError):
         filters.erb_filterbank(np.zeros((2, 2)), co)
+
+
+def _fb(waves, coefs, split):
+    old = os.environ.get("F2CNN_K1_SPLIT")
+    os.environ["F2CNN_K1_SPLIT"] = split
+    try:
+        return filters.erb_filterbank_batch(waves, coefs)
+    finally:
+        if old is None:
+            del os.environ["F2CNN_K1_SPLIT"]
+        else:
+            os.environ["F2CNN_K1_SPLIT"] = old
+
+
+@pytest.mark.parametrize("C", [64, 128, 8])
+def test_time_split_path_for_small_batches(C):
+    """B = 1 (cfg1, `cnn eval` of one file) runs the filterbank time-split (segments chained through T^L): same
+    results as the serial kernel to float64 rounding, and as the oracle to the parity bar; ragged batches, forced
+    segment counts, float64 input."""
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
+    wave = orc.synth_utterance(1234, 16000)
+    serial = _fb([wave], coefs, "0")[0]
+    for k in ("", "2", "5", "32"):
+        split = _fb([wave], coefs, k)[0] if k else filters.erb_filterbank(wave, coefs)     # "": the default policy
+        assert chan_relerr(split, serial) <= 1e-11, k
+    assert chan_relerr(filters.erb_filterbank(wave, coefs), orc.erb_filterbank(wave, coefs)) <= 1e-9
+    # ragged: lengths around the segment and tile boundaries, one too short to be split, float64 samples
+    rng = np.random.default_rng(5)
+    waves = [orc.synth_utterance(10 + i, n) for i, n in enumerate((4097, 300, 31, 8192, 5000, 1))]
+    for k in ("3", "7", ""):
+        got = _fb(waves, coefs, k) if k else filters.erb_filterbank_batch(waves, coefs)
+        for w, g in zip(waves, got):
+            assert g.shape == (C, len(w))
+            assert chan_relerr(g, orc.erb_filterbank(w, coefs)) <= 1e-9
+    noisy = [w.astype(np.float64) + rng.standard_normal(len(w)) for w in waves[:4]]
+    for g, w in zip(_fb(noisy, coefs, "4"), noisy):
+        assert chan_relerr(g, orc.erb_filterbank(w, coefs)) <= 1e-9
