@@ -531,7 +531,8 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         if (g.empty()) continue;
         P.ulist = identity ? nullptr : d_lists + pos;
         pos += g.size();
-        const int nthreads = (log2h == 14 && precision == F2_FFT_F32) ? 1024 : log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
+        const int nthreads = (log2h == 14 && precision == F2_FFT_F32) ? 1024
+                             : (log2h == 13 && precision == F2_FFT_F32) ? F2_THREADS13 : log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
         const dim3 grid((unsigned)(g.size() * (size_t)C)), block(nthreads);
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
         if (precision == F2_FFT_F32) {

@@ -11,13 +11,21 @@ namespace f2fft {
 #ifndef F2_PLAN13_PASSES
 #define F2_PLAN13_PASSES 4
 #endif
+#ifndef F2_THREADS13       // workgroup size of the H = 8192 float transform (diagnostic variants: 256)
+#define F2_THREADS13 512
+#endif
+#ifndef F2_MINWAVES13
+#define F2_MINWAVES13 4
+#endif
 // threads per workgroup: 256, or 512 where 256 threads would need more than 256 registers each
 template <typename F, int LOG2H>
-constexpr int threads_for() { return (LOG2H == 14 && sizeof(F) == 4) ? 1024 : LOG2H >= 13 ? 512 : 256; }
+constexpr int threads_for() {
+    return (LOG2H == 14 && sizeof(F) == 4) ? 1024 : (LOG2H == 13 && sizeof(F) == 4) ? F2_THREADS13 : LOG2H >= 13 ? 512 : 256;
+}
 // waves per SIMD the register allocator must leave room for (2 workgroups per CU wherever LDS allows)
 template <typename F, int LOG2H>
 constexpr int min_waves_for() {
-    return (sizeof(F) == 4 && (LOG2H == 13 || LOG2H == 14)) ? 4 : (sizeof(F) == 4 && LOG2H <= 12) ? 2 : (sizeof(F) == 8 && LOG2H <= 12) ? 2 : 2;
+    return (sizeof(F) == 4 && LOG2H == 13) ? F2_MINWAVES13 : (sizeof(F) == 4 && LOG2H == 14) ? 4 : 2;
 }
 
 // Whether pass 0 derives its 15 twiddles per butterfly from two loaded ones (radix-16 first pass, float transforms)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>   -> gpurun_out/<tag>/...
+# The rocprofv3 runs behind profiles/<tag>_*: kernel-trace stats of the cfg3 and cfg4 bench commands, the HBM traffic
+# counters (separate --pmc passes), the SQ counters of the bound sheet, and the plain default line.
+set -e
+tag=$1
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python3 bench.py --steps 20 --warmup 5 > $out/bench_default_line.json 2> $out/bench_default.err
+echo "default line done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_cfg3 -- python3 bench.py --workload cfg3 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_cfg3_line.json 2> $out/kt_cfg3.err
+echo "cfg3 trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_cfg4 -- python3 bench.py --workload cfg4 --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_cfg4_line.json 2> $out/kt_cfg4.err
+echo "cfg4 trace done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --workload cfg3 --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_$c.log 2>&1
+done
+echo "traffic done"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $out/pmc_sq1 -- python3 bench.py --workload cfg3 --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_sq1.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq2 -- python3 bench.py --workload cfg3 --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_sq2.log 2>&1
+python3 tools/pmc_summary.py $out/pmc_sq1 $out/pmc_sq2 > $out/pmc_sq_summary.txt
+python3 tools/make_traffic_json.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/traffic_cfg3.json > /dev/null
+find $out/kt_cfg3 -name "*kernel_stats.csv" -exec cp {} $out/bench_cfg3_kernel_stats.csv \;
+find $out/kt_cfg4 -name "*kernel_stats.csv" -exec cp {} $out/bench_cfg4_kernel_stats.csv \;
+F2CNN_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --corpus 2000 > $out/bench_2rank_one_device_line.json 2> $out/bench_2rank.err
+./tools/ubench/fma64_operands > $out/ubench_fma64.txt 2>&1 || true
+echo "all done"
