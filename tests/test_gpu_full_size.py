@@ -42,9 +42,16 @@ def test_cfg2_filterbank_full_batch(corpus):
     for b in (0, 100, 255):
         got = fetch_rows(ctx, d_gfb, b, rows)
         assert chan_relerr(got, orc.erb_filterbank(waves[b], coefs[rows])) <= 1e-9
-    # batching must not matter: utterance 255 alone gives the same bits as inside the batch
-    alone = filters.erb_filterbank(waves[255], coefs)
+    # batching must not matter: utterance 255 alone gives the same bits as inside the batch when it runs the same
+    # (serial) kernel, and the same values to float64 rounding through the time-split path a single utterance takes
+    import os
+    os.environ["F2CNN_K1_SPLIT"] = "0"
+    try:
+        alone = filters.erb_filterbank(waves[255], coefs)
+    finally:
+        del os.environ["F2CNN_K1_SPLIT"]
     np.testing.assert_array_equal(alone[rows], fetch_rows(ctx, d_gfb, 255, rows))
+    assert chan_relerr(filters.erb_filterbank(waves[255], coefs)[rows], alone[rows]) <= 1e-11
     # no element left untouched anywhere in the 4.2 GB output (sum of a checksum per utterance is finite)
     whole = np.empty((C, N))
     sums = []
@@ -77,3 +84,77 @@ def test_cfg3_fused_slice_matches_two_step_and_oracle(corpus):
         assert (fused > 0).all()                    # envelopes of noise are strictly positive (normalizeInput needs it)
     ctx.free(d_env)
     ctx.free(d_ref)
+
+
+def test_cfg3_full_batch_of_1000():
+    """The benchmark's own workload (bench.py default: 1000 x 1 s, seed 2027, 128 channels, LPF 50, float32 FFT) through
+    the fused call: spot rows against the oracle, every output element written, finite and positive."""
+    ctx = _lib.default_context()
+    Bf = 1000
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
+    waves = bench.synth_batch(2027, 0, Bf, N)
+    off = np.arange(Bf + 1, dtype=np.int64) * N
+    d_wave, d_env = ctx.malloc(waves.nbytes), ctx.malloc(8 * Bf * C * N)
+    ctx.h2d(d_wave, waves)
+    ctx.memset(d_env, 0xFF, 8 * Bf * C * N)
+    ctx.filterbank_envelope_fused(d_wave, _lib.WAVE_I16, off, coefs, Bf, C, True, 50.0, _lib.FFT_F32, d_env, None,
+                                  _lib.MEM_DEVICE)
+    ctx.synchronize()
+    rows = [0, 64, 126, 127]
+    for b in (0, 499, 999):
+        ref = orc.extract_envelope_from_matrix(orc.erb_filterbank(waves[b], coefs[rows]), True, 50)
+        assert chan_relerr(fetch_rows(ctx, d_env, b, rows), ref) <= 1e-5
+    whole = np.empty((C, N))
+    total = 0.0
+    for b in range(0, Bf, 41):
+        ctx.d2h(whole, d_env + 8 * b * C * N)
+        assert np.isfinite(whole).all() and (whole > 0).all()
+        total += float(whole.sum())
+    assert np.isfinite(total)
+    ctx.free(d_wave)
+    ctx.free(d_env)
+
+
+@pytest.mark.parametrize("workload", ["cfg5", "cfg5r"])
+def test_cfg5_corpus_sharded_over_two_ranks(workload):
+    """BASELINE config 5 in miniature, through bench.py's own job object: the corpus (utterance u = seed 2029 + u;
+    cfg5r: U[16000, 64000] samples) sharded r::2, every utterance processed exactly once, envelopes equal to the
+    oracle and bit-identical to what a single rank computes for the same utterance (sharding and batching do not
+    change results)."""
+    ctx = _lib.default_context()
+    corpus, Cc = 12, 128
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, Cc, 100))
+    all_lens = bench.ragged_lengths(2029, corpus) if workload == "cfg5r" else np.full(corpus, N, np.int64)
+
+    def run(world):
+        out = {}
+        for rank in range(world):
+            idx = np.arange(corpus)[rank::world]
+            lens = all_lens[idx]
+            waves = bench.synth_corpus(2029, idx, lens, 1)
+            job = bench.DspJob(ctx, coefs, Cc, waves, lens, 5, "both", 50, _lib.FFT_F32)   # launches of <= 5 utterances
+            job.step()
+            ctx.synchronize()
+            assert sum(nb for _, _, nb in job.batches) == len(idx)
+            pos = 0
+            for (w0, off, nb), dst in zip(job.batches, job.out_ptr):
+                for k in range(nb):
+                    u = int(idx[pos + k])
+                    n = int(off[k + 1] - off[k])
+                    env = np.empty((Cc, n))
+                    ctx.d2h(env, dst + 8 * Cc * int(off[k]))
+                    assert u not in out
+                    out[u] = env
+                pos += nb
+            job.free()
+        return out
+
+    one, two = run(1), run(2)
+    assert sorted(one) == sorted(two) == list(range(corpus))
+    for u in range(corpus):
+        np.testing.assert_array_equal(one[u], two[u])
+    rows = [0, 63, 127]
+    for u in (0, 5, 11):
+        wave = bench.synth_utterance(2029 + u, int(all_lens[u]))
+        ref = orc.extract_envelope_from_matrix(orc.erb_filterbank(wave, coefs[rows]), True, 50)
+        assert chan_relerr(one[u][rows], ref) <= 1e-5, (workload, u)
