@@ -145,9 +145,11 @@ int f2_ctx_destroy(f2_ctx* ctx) {
             if (s.ptr) (void)hipFree(s.ptr);
     for (f2_scratch& s : ctx->tw_split)
         if (s.ptr) (void)hipFree(s.ptr);
+    if (ctx->tw_pair.ptr) (void)hipFree(ctx->tw_pair.ptr);
     if (ctx->work3.ptr) (void)hipFree(ctx->work3.ptr);
     if (ctx->k1_states.ptr) (void)hipFree(ctx->k1_states.ptr);
     if (ctx->k1_mtab.ptr) (void)hipFree(ctx->k1_mtab.ptr);
+    if (ctx->k1_order.ptr) (void)hipFree(ctx->k1_order.ptr);
     if (ctx->handoff.ptr) (void)hipFree(ctx->handoff.ptr);
     if (ctx->handoff_off.ptr) (void)hipFree(ctx->handoff_off.ptr);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
@@ -385,8 +387,10 @@ int f2_plan_handoff(f2_ctx* ctx, const int64_t* h_offsets, int B, int C, int pre
     F2_TRY(f2_reserve(ctx, ctx->handoff_off, sizeof(int64_t) * (size_t)B));
     F2_HIP(ctx, hipMemcpyAsync(ctx->handoff_off.ptr, off.data(), sizeof(int64_t) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
     F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `off` is a local
+    ctx->handoff_off_host = off;
     plan->d_x32 = (float*)ctx->handoff.ptr;
     plan->d_x32_off = (const int64_t*)ctx->handoff_off.ptr;
+    plan->h_x32_off = ctx->handoff_off_host.data();
     return F2_OK;
 }
 
@@ -442,9 +446,13 @@ int f2_envelope_batch(f2_ctx* ctx, const double* gfb, const int64_t* offsets, in
     const size_t bytes = sizeof(double) * (size_t)C * (size_t)total;
     const bool staged = mem_space != F2_MEM_DEVICE;
     if (staged) {
+        // separate device buffers for the filterbank rows and the envelopes: rows of 32769..65536 samples then take the
+        // on-chip path (which parks intermediate data in the output rows) exactly as they do inside the fused call
+        F2_TRY(f2_reserve(ctx, ctx->stage_aux, bytes));
         F2_TRY(f2_reserve(ctx, ctx->stage_out, bytes));
-        F2_HIP(ctx, hipMemcpyAsync(ctx->stage_out.ptr, gfb, bytes, hipMemcpyHostToDevice, ctx->stream));
-        d_gfb = d_env = (double*)ctx->stage_out.ptr;  // in place on the device
+        F2_HIP(ctx, hipMemcpyAsync(ctx->stage_aux.ptr, gfb, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_gfb = (const double*)ctx->stage_aux.ptr;
+        d_env = (double*)ctx->stage_out.ptr;
     }
     F2_TRY(f2_launch_envelope(ctx, d_gfb, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz,
                               fft_precision, d_env));

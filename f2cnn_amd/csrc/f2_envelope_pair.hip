@@ -1,0 +1,317 @@
+// K2 for rows of 32769..65536 samples (most TIMIT sentences: 2-4 s at 16 kHz), float transforms: the whole row stays on
+// the chip. Same mathematics as f2_envelope.hip (reference: scripts/processing/EnvelopeExtraction.py:20-67).
+//
+// M = 65536 needs two complex transforms of H = 32768 points = 256 KB, more than the 160 KB of LDS. One radix-2 stage
+// at each end splits them into two INDEPENDENT sub-rows of HS = 16384 points that the LDS-resident machinery of
+// f2_fft_lds.h transforms one after the other inside the same 1024-thread workgroup:
+//
+//   load      z[m] = x[2m] + i x[2m+1];  a[m] = z[m] + z[m+HS],  b[m] = (z[m] - z[m+HS]) e^{-2 pi i m / H}   (DIF stage)
+//             => Z[2j] = FFT_HS(a)[j],  Z[2j+1] = FFT_HS(b)[j]
+//   pair step W[k] = i sin(t_k) Z[k] + cos(t_k) conj(Z[H-k]),  t_k = pi k / H,  W[0] = 0  (as f2_envelope.hip) never
+//             mixes parities: H - 2j = 2 (HS - j) and H - (2j+1) = 2 (HS-1-j) + 1. The even sub-row is exactly the pair
+//             step of an HS-point row (t = pi j / HS); the odd one pairs j with HS-1-j at t = pi (2j+1) / H
+//   inverse   conj(w[m]) = FFT_H(conj(W)/H)[m] = (E[m] + e^{-2 pi i m / H} O[m]) / 2,  conj(w[m+HS]) = (E[m] - ... O[m]) / 2
+//             with E, O = FFT_HS of the two conjugated, 1/HS-scaled sub-spectra (DIT stage); only squares of w are used
+//
+// While one sub-row is in LDS the other one (b, then E) is parked in the row's own float64 OUTPUT slot - 8 n >= 2 * 128 KB
+// bytes that nothing reads before this workgroup overwrites them with the envelopes, and that stay in L2 / Infinity Cache
+// for the ~100 us in between. This requires the input not to live there: the filterbank's float32 hand-off of such rows
+// is a compact scratch row anyway (f2_plan_handoff), and float64 input qualifies when gfb != env; in-place float64 calls
+// keep the four-step path (f2_envelope_split.hip). HBM bytes per sample-channel: 4 (or 8) read twice + 8 written,
+// against 44-48 for the four-step path.
+#include <algorithm>
+
+#include "f2_fft_lds.h"
+
+using namespace f2fft;
+
+namespace {
+
+constexpr int LOG2S = 14;
+constexpr int HS = 1 << LOG2S;
+constexpr int NT = 1024;
+constexpr int PT = plan_points_per_thread(LOG2S, NT);
+constexpr int R0 = 1 << plan_bits(LOG2S, 0);
+constexpr int NB0 = HS / R0;
+#ifndef F2_PAIR_LOADCHUNK
+#define F2_PAIR_LOADCHUNK 8
+#endif
+constexpr int LOADCHUNK = F2_PAIR_LOADCHUNK;   // points whose loads are in flight together in the two radix-2 stages
+static_assert(PT == R0 && NB0 == NT, "one radix-16 butterfly per thread in the first and last pass");
+
+struct PairParams {
+    const double* gfb;
+    double* env;
+    const int64_t* offsets;
+    const int* ulist;          // utterances of this launch (device)
+    int C;
+    int lpf;
+    double b0, a1;
+    const float* x32;          // float32 hand-off of the filterbank: compact (C, n) rows at x32 + x32_off[b], or NULL
+    const int64_t* x32_off;
+    const cpx<float>* tx;      // [HS]   exp(-2 pi i m / H) = (cos, -sin)(pi m / HS)
+    const cpx<float>* vo;      // [HS/2] (cos, -sin)(pi (2j+1) / H): pair-step angles of the odd sub-row
+};
+
+// samples i0, i0 + 1 (i0 even) of a row of n samples as floats, 0 beyond the end; clamped addresses, no divergent
+// loads. EVEN: n is even and the row is aligned for one load per pair.
+template <typename T, bool EVEN>
+__device__ __forceinline__ cpx<float> load_pair(const T* __restrict__ x, int n, int i0) {
+    if constexpr (EVEN) {
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        const T2 t = *reinterpret_cast<const T2*>(x + min(i0, n - 2));
+        return {i0 < n ? (float)t.x : 0.f, i0 < n ? (float)t.y : 0.f};
+    } else {
+        const T va = x[min(i0, n - 1)], vb = x[min(i0 + 1, n - 1)];
+        return {i0 < n ? (float)va : 0.f, i0 + 1 < n ? (float)vb : 0.f};
+    }
+}
+
+// forward transform of the sub-row in v, Hilbert pair step in LDS, second transform back into v
+template <bool ODD>
+__device__ __forceinline__ void sub_row(cpx<float>* lds, const cpx<float>* __restrict__ tw, const cpx<float>* twl,
+                                        const cpx<float>* __restrict__ vo, int tid, cpx<float> (&v)[PT]) {
+    constexpr bool T0R = derive_tw0<float, LOG2S>();
+    fft_all<float, LOG2S, false, PT, NT, T0R>(lds, tw, twl, tid, v);       // spectrum at lds[cpad(k)]
+    const float sc = 1.0f / (float)HS;
+    if constexpr (!ODD) {
+        const cpx<float>* __restrict__ V = tw + plan_tw_total(LOG2S);      // (cos, -sin)(pi k / HS), k <= HS/2
+        constexpr int NPAIR = HS / 2 - 1, ITERP = (NPAIR + NT - 1) / NT;
+        cpx<float> zk[ITERP], zh[ITERP], vk[ITERP];
+#pragma unroll
+        for (int i = 0; i < ITERP; ++i) {
+            const int k = min(1 + tid + i * NT, HS / 2 - 1);
+            zk[i] = lds[cpad(k)];
+            zh[i] = lds[cpad(HS - k)];
+            vk[i] = V[k];
+        }
+#pragma unroll
+        for (int i = 0; i < ITERP; ++i) {
+            const int k = 1 + tid + i * NT;
+            const float cs = vk[i].re * sc, sn = -vk[i].im * sc;
+            if (k < HS / 2) {
+                lds[cpad(k)] = {-sn * zk[i].im + cs * zh[i].re, -(sn * zk[i].re - cs * zh[i].im)};
+                lds[cpad(HS - k)] = {-sn * zh[i].im - cs * zk[i].re, -(sn * zh[i].re + cs * zk[i].im)};
+            }
+        }
+        if (tid == 0) {
+            const cpx<float> zq = lds[cpad(HS / 2)];                       // t = pi/2: W = i Z
+            lds[cpad(HS / 2)] = {-zq.im * sc, -zq.re * sc};
+            lds[cpad(0)] = {0.f, 0.f};
+        }
+    } else {
+        constexpr int ITERP = (HS / 2) / NT;                               // pairs (j, HS-1-j), j < HS/2
+        cpx<float> zk[ITERP], zh[ITERP], vk[ITERP];
+#pragma unroll
+        for (int i = 0; i < ITERP; ++i) {
+            const int j = tid + i * NT;
+            zk[i] = lds[cpad(j)];
+            zh[i] = lds[cpad(HS - 1 - j)];
+            vk[i] = vo[j];
+        }
+#pragma unroll
+        for (int i = 0; i < ITERP; ++i) {
+            const int j = tid + i * NT;
+            const float cs = vk[i].re * sc, sn = -vk[i].im * sc;
+            lds[cpad(j)] = {-sn * zk[i].im + cs * zh[i].re, -(sn * zk[i].re - cs * zh[i].im)};
+            lds[cpad(HS - 1 - j)] = {-sn * zh[i].im - cs * zk[i].re, -(sn * zh[i].re + cs * zk[i].im)};
+        }
+    }
+    __syncthreads();
+    fft_all<float, LOG2S, true, PT, NT, T0R>(lds, tw, twl, tid, v);        // point tid + j*NB0 in v[brev<R0>(j)]
+}
+
+// T: float (the filterbank's compact float32 hand-off rows) or double (a float64 filterbank matrix); EVEN: every row of
+// the launch has an even length and starts on a 2-element boundary, so a pair is one load (the host groups the utterances).
+template <typename T, bool EVEN>
+__global__ __launch_bounds__(NT, 4) void k_envelope_pair(PairParams P, const cpx<float>* __restrict__ tw) {
+    constexpr int CS = cpad_size(HS);
+    constexpr int TWL = plan_tw_lds_count(LOG2S);
+    constexpr size_t LP = lowpass_lds_bytes<float, NT, R0>();
+    constexpr size_t LDS_BYTES = sizeof(cpx<float>) * CS > LP ? sizeof(cpx<float>) * CS : LP;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) cpx<float> twl[TWL > 0 ? TWL : 1];
+    __shared__ float e_mid;
+
+    const int tid = threadIdx.x;
+    const int u = blockIdx.x / P.C, c = blockIdx.x - u * P.C;
+    const int b = P.ulist[u];
+    const int64_t off = P.offsets[b];
+    const int n = (int)(P.offsets[b + 1] - off);
+    const size_t row = (size_t)P.C * (size_t)off + (size_t)c * (size_t)n;
+    for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2S, 1) + i];
+    double* __restrict__ y = P.env + row;
+    const T* __restrict__ x;
+    if constexpr (sizeof(T) == 4)
+        x = reinterpret_cast<const T*>(P.x32 + P.x32_off[b] + (size_t)c * (size_t)n);
+    else
+        x = reinterpret_cast<const T*>(P.gfb + row);
+    float* e_mid_p = &e_mid;
+    cpx<float>* lds = reinterpret_cast<cpx<float>*>(smem);
+    cpx<float>* park_b = reinterpret_cast<cpx<float>*>(y);      // b: [0, 128 KB) of the row's output slot
+    cpx<float>* park_e = park_b + HS;                           // E: [128 KB, 256 KB)
+
+    // load + first radix-2 stage; point j of this thread is m = tid + j * NB0. A few points at a time: with all 16
+    // in flight the loads alone would hold 96 registers.
+    cpx<float> v[PT];
+#pragma unroll
+    for (int j0 = 0; j0 < R0; j0 += LOADCHUNK) {
+#pragma unroll
+        for (int j = j0; j < j0 + LOADCHUNK; ++j) {
+            const int m = tid + j * NB0;
+            const cpx<float> z0 = load_pair<T, EVEN>(x, n, 2 * m), z1 = load_pair<T, EVEN>(x, n, 2 * (m + HS));
+            v[j] = z0 + z1;
+            park_b[m] = cmul(z0 - z1, P.tx[m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    sub_row<false>(lds, tw, twl, P.vo, tid, v);
+#pragma unroll
+    for (int j = 0; j < R0; ++j) park_e[tid + j * NB0] = v[brev<R0>(j)];
+#pragma unroll
+    for (int j = 0; j < R0; ++j) v[j] = park_b[tid + j * NB0];       // this thread's own stores: no synchronisation
+    sub_row<true>(lds, tw, twl, P.vo, tid, v);
+
+    // last radix-2 stage + magnitude: lower half of the row from E + T O, upper half from E - T O. The lower half's
+    // envelopes stay in registers until every thread has read its parked points (they overwrite the parking area);
+    // the upper half's positions lie beyond it and are written at once - final float64 values without low-pass, else
+    // the float pair at the start of its own 16-byte output position, where it waits for the second low-pass segment.
+    const bool pairs_ok = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    float er[R0], ei[R0];
+#pragma unroll
+    for (int j0 = 0; j0 < R0; j0 += 4) {
+#pragma unroll
+        for (int j = j0; j < j0 + 4; ++j) {
+            int m = tid + j * NB0;
+            asm volatile("" : "+v"(m));       // (keeps the compiler from holding the load stage's 32 addresses until here)
+            const cpx<float> e = park_e[m];
+            const cpx<float> o = cmul(v[brev<R0>(j)], P.tx[m]);
+            const cpx<float> x0 = load_pair<T, EVEN>(x, n, 2 * m), x1 = load_pair<T, EVEN>(x, n, 2 * (m + HS));
+            const float lr = 0.5f * (e.re + o.re), li = 0.5f * (e.im + o.im);
+            const float ur = 0.5f * (e.re - o.re), ui = 0.5f * (e.im - o.im);
+            er[j] = fsqrt(x0.re * x0.re + lr * lr);
+            ei[j] = fsqrt(x0.im * x0.im + li * li);
+            const float hr = fsqrt(x1.re * x1.re + ur * ur), hi = fsqrt(x1.im * x1.im + ui * ui);
+            const int i1 = 2 * (m + HS);
+            if (P.lpf) {
+                if (i1 < n) *reinterpret_cast<cpx<float>*>(y + i1) = {hr, hi};
+            } else if (pairs_ok && i1 + 1 < n) {
+                *reinterpret_cast<double2*>(y + i1) = make_double2((double)hr, (double)hi);
+            } else {
+                if (i1 < n) y[i1] = (double)hr;
+                if (i1 + 1 < n) y[i1 + 1] = (double)hi;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid == NT - 1) *e_mid_p = ei[R0 - 1];   // envelope sample 2 HS - 1: e[n-1] entering the upper half's low-pass
+    __syncthreads();   // every read of the parked sub-rows (and the last LDS reads) precedes the stores over them
+    if (!P.lpf) {
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+            const int i0 = 2 * (tid + j * NB0);              // i0 + 1 < 2 HS < n
+            if (pairs_ok) {
+                *reinterpret_cast<double2*>(y + i0) = make_double2((double)er[j], (double)ei[j]);
+            } else {
+                y[i0] = (double)er[j];
+                y[i0 + 1] = (double)ei[j];
+            }
+        }
+        return;
+    }
+    const double ycarry = lowpass_pairs_store<float, NT, R0>(er, ei, P.a1, P.b0, smem, y, 2 * HS, pairs_ok, tid);
+#pragma unroll
+    for (int j = 0; j < R0; ++j) {
+        const int i1 = 2 * (tid + j * NB0 + HS);
+        const cpx<float> p = i1 < n ? *reinterpret_cast<const cpx<float>*>(y + i1) : cpx<float>{0.f, 0.f};
+        er[j] = p.re;
+        ei[j] = i1 + 1 < n ? p.im : 0.f;
+    }
+    __syncthreads();   // the scan's last LDS reads precede the next segment's writes
+    lowpass_pairs_store<float, NT, R0>(er, ei, P.a1, P.b0, smem, y + 2 * HS, n - 2 * HS, pairs_ok && ((n & 1) == 0), tid,
+                                       ycarry, *e_mid_p);
+}
+
+int ensure_pair_tables(f2_ctx* ctx) {
+    if (ctx->tw_pair.ptr) return F2_OK;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    std::vector<cpx<float>> host((size_t)HS + HS / 2);
+    for (int m = 0; m < HS; ++m) {
+        const long double ang = pi * (long double)m / (long double)HS;
+        host[(size_t)m] = {(float)cosl(ang), (float)(-sinl(ang))};
+    }
+    for (int j = 0; j < HS / 2; ++j) {
+        const long double ang = pi * (long double)(2 * j + 1) / (long double)(2 * HS);
+        host[(size_t)HS + j] = {(float)cosl(ang), (float)(-sinl(ang))};
+    }
+    F2_TRY(f2_reserve(ctx, ctx->tw_pair, sizeof(cpx<float>) * host.size()));
+    F2_HIP(ctx, hipMemcpyAsync(ctx->tw_pair.ptr, host.data(), sizeof(cpx<float>) * host.size(), hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F2_OK;
+}
+
+}  // namespace
+
+// Rows of 2^15 complex points (32768 < n <= 65536), float transforms, input not aliased with the output rows.
+bool f2_envelope_pair_supports(int log2h, int precision) { return precision == F2_FFT_F32 && log2h == LOG2S + 1; }
+
+int f2_launch_envelope_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets,
+                            const int64_t* h_offsets, const int* utts, int nutt, int C, int lpf, double b0, double a1,
+                            const float* d_x32, const int64_t* d_x32_off, const int64_t* h_x32_off) {
+    if (nutt <= 0) return F2_OK;
+    F2_CHECK(ctx, d_x32 || d_gfb != d_env, F2_ERR_INVALID, "the on-chip path for 32769..65536-sample rows cannot run in place");
+    F2_TRY(ensure_pair_tables(ctx));
+    F2_TRY(ensure_twiddles<float>(ctx, LOG2S, ctx->tw[0][LOG2S]));
+    // utterances whose rows all have an even length and start on an even element first: their pairs are single loads
+    std::vector<int> order;
+    order.reserve((size_t)nutt);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < nutt; ++i) {
+            const int b = utts[i];
+            const int64_t n = h_offsets[b + 1] - h_offsets[b];
+            const int64_t base = d_x32 ? h_x32_off[b] : (int64_t)C * h_offsets[b];
+            const bool even = (n % 2 == 0) && (base % 2 == 0);
+            if (even == (pass == 0)) order.push_back(b);
+        }
+    int n_even = 0;
+    for (int b : order) {
+        const int64_t n = h_offsets[b + 1] - h_offsets[b];
+        const int64_t base = d_x32 ? h_x32_off[b] : (int64_t)C * h_offsets[b];
+        if ((n % 2 == 0) && (base % 2 == 0)) ++n_even;
+    }
+    F2_TRY(f2_reserve(ctx, ctx->work3, sizeof(int) * (size_t)nutt));
+    F2_HIP(ctx, hipMemcpyAsync(ctx->work3.ptr, order.data(), sizeof(int) * (size_t)nutt, hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `order` is a local
+    PairParams P;
+    P.gfb = d_gfb;
+    P.env = d_env;
+    P.offsets = d_offsets;
+    P.ulist = nullptr;
+    P.C = C;
+    P.lpf = lpf;
+    P.b0 = b0;
+    P.a1 = a1;
+    P.x32 = d_x32;
+    P.x32_off = d_x32_off;
+    P.tx = (const cpx<float>*)ctx->tw_pair.ptr;
+    P.vo = P.tx + HS;
+    for (int even = 0; even < 2; ++even) {
+        const int cnt = even ? n_even : nutt - n_even;
+        if (cnt == 0) continue;
+        P.ulist = (const int*)ctx->work3.ptr + (even ? 0 : n_even);
+        const dim3 grid((unsigned)((size_t)cnt * C)), block(NT);
+        const cpx<float>* tw = (const cpx<float>*)ctx->tw[0][LOG2S].ptr;
+        F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
+        if (d_x32 && even)
+            hipLaunchKernelGGL((k_envelope_pair<float, true>), grid, block, 0, ctx->stream, P, tw);
+        else if (d_x32)
+            hipLaunchKernelGGL((k_envelope_pair<float, false>), grid, block, 0, ctx->stream, P, tw);
+        else if (even)
+            hipLaunchKernelGGL((k_envelope_pair<double, true>), grid, block, 0, ctx->stream, P, tw);
+        else
+            hipLaunchKernelGGL((k_envelope_pair<double, false>), grid, block, 0, ctx->stream, P, tw);
+        F2_HIP(ctx, hipGetLastError());
+        F2_TRY(f2_prof_end(ctx, F2_K_ENVELOPE));
+    }
+    return F2_OK;
+}

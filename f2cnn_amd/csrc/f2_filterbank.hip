@@ -64,37 +64,26 @@ struct SplitArgs {
     int L;                  // samples per segment (multiple of TB)
     double* states;         // [unit][K][8][64 lanes]: E of every segment
     const double* mtab;     // [C][8][8]: M = T^L, row major
+    const int* order;       // MODE 3: units in the order they are handed out (longest first)
+    int* queue;             // MODE 3: next position in `order` (zeroed before the launch)
 };
 
+// One unit of work = (utterance, group of 64 channels[, segment]) on one wave.
 template <typename WaveT, typename OutT, bool A2ZERO, int MODE>
-__global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_filterbank(const WaveT* __restrict__ wave,
-                                                       const int64_t* __restrict__ offsets,
-                                                       const double* __restrict__ coefs, int C,
-                                                       int groups, int units, double* __restrict__ out,
-                                                       float* __restrict__ alt, const int64_t* __restrict__ alt_off,
-                                                       SplitArgs sp) {
-    static_assert(MODE == 0 || A2ZERO, "the time-split path uses the direct-form-II state words");
-    constexpr int WPB = waves_per_block<OutT, MODE>();
-    __shared__ OutT tiles[WPB][64][TB + 1];
-    __shared__ double xss[WPB][TB];
-    __shared__ double msh[MODE == 2 ? WPB : 1][MODE == 2 ? 64 : 1][64];   // M of this wave's channels, [entry][lane]
-
-    const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
-    const int useg = blockIdx.x * WPB + wid;          // (utterance, group of 64 channels[, segment])
-    const int K = MODE == 0 ? 1 : sp.K;
-    const int unit = MODE == 0 ? useg : useg / K;
-    const int seg = MODE == 0 ? 0 : useg - unit * K;
-    if (unit >= units) return;                       // whole wave: the waves of a workgroup never meet at a barrier
-    OutT (*tile)[TB + 1] = tiles[wid];
-    double* xs = xss[wid];
+__device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, const int64_t* __restrict__ offsets,
+                                                const double* __restrict__ coefs, int C, int groups,
+                                                double* __restrict__ out, float* __restrict__ alt,
+                                                const int64_t* __restrict__ alt_off, const SplitArgs& sp, int unit, int seg,
+                                                int lane, int wid, OutT (*tile)[TB + 1], double* xs,
+                                                double (*mshw)[64]) {
+    const int K = (MODE == 1 || MODE == 2) ? sp.K : 1;
     const int b = unit / groups;
     const int c0 = (unit % groups) * 64;
     const int64_t off = offsets[b];
     const int64_t N = offsets[b + 1] - off;
     if (N <= 0) return;
-    const int64_t t_begin = MODE == 0 ? 0 : (int64_t)seg * sp.L;
-    const int64_t t_end = MODE == 0 ? N : min(N, t_begin + sp.L);
+    const int64_t t_begin = (MODE == 1 || MODE == 2) ? (int64_t)seg * sp.L : 0;
+    const int64_t t_end = (MODE == 1 || MODE == 2) ? min(N, t_begin + sp.L) : N;
     if (t_begin >= N) return;
 
     const int c = min(c0 + lane, C - 1);  // idle lanes shadow the last channel; their rows are never stored
@@ -116,7 +105,7 @@ __global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_fi
             // true state entering this segment: S_j = M S_(j-1) + E_(j-1), S_0 = 0
             const double* mrow = sp.mtab + (size_t)c * 64;
 #pragma unroll 8
-            for (int i = 0; i < 64; ++i) msh[wid][i][lane] = mrow[i];
+            for (int i = 0; i < 64; ++i) mshw[i][lane] = mrow[i];
             wave_sync();
             double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const double* e = sp.states + ((size_t)unit * K) * 8 * 64 + lane;
@@ -126,7 +115,7 @@ __global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_fi
                 for (int r = 0; r < 8; ++r) {
                     double acc = e[r * 64];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc = fma(msh[wid][r * 8 + q][lane], S[q], acc);
+                    for (int q = 0; q < 8; ++q) acc = fma(mshw[r * 8 + q][lane], S[q], acc);
                     Sn[r] = acc;
                 }
 #pragma unroll
@@ -275,11 +264,55 @@ __global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_fi
     }
 }
 
+// MODE 0: one unit per wave, unit = wave index. MODE 1 / 2: the two passes of the time-split path. MODE 3: the waves
+// pull units from a queue (sp.order lists them longest first, sp.queue counts): a ragged batch whose waves would
+// otherwise finish with the longest utterance of their SIMD.
+template <typename WaveT, typename OutT, bool A2ZERO, int MODE>
+__global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_filterbank(const WaveT* __restrict__ wave,
+                                                       const int64_t* __restrict__ offsets,
+                                                       const double* __restrict__ coefs, int C,
+                                                       int groups, int units, double* __restrict__ out,
+                                                       float* __restrict__ alt, const int64_t* __restrict__ alt_off,
+                                                       SplitArgs sp) {
+    static_assert(MODE == 0 || A2ZERO, "the time-split and queue paths use the direct-form-II kernel");
+    constexpr int WPB = waves_per_block<OutT, MODE>();
+    __shared__ OutT tiles[WPB][64][TB + 1];
+    __shared__ double xss[WPB][TB];
+    __shared__ double msh[MODE == 2 ? WPB : 1][MODE == 2 ? 64 : 1][64];   // M of this wave's channels, [entry][lane]
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    if constexpr (MODE == 3) {
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(sp.queue, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= units) return;
+            filterbank_unit<WaveT, OutT, A2ZERO, MODE>(wave, offsets, coefs, C, groups, out, alt, alt_off, sp, sp.order[t], 0,
+                                                       lane, wid, tiles[wid], xss[wid], msh[0]);
+        }
+    } else {
+        const int useg = blockIdx.x * WPB + wid;          // (utterance, group of 64 channels[, segment])
+        const int K = MODE == 0 ? 1 : sp.K;
+        const int unit = useg / K;
+        if (unit >= units) return;                        // whole wave: the waves of a workgroup never meet at a barrier
+        filterbank_unit<WaveT, OutT, A2ZERO, MODE>(wave, offsets, coefs, C, groups, out, alt, alt_off, sp, unit,
+                                                   useg - unit * K, lane, wid, tiles[wid], xss[wid], msh[MODE == 2 ? wid : 0]);
+    }
+}
+
 template <typename WaveT, typename OutT>
 void launch_fb(hipStream_t st, int units, bool a2zero, const void* wave, const int64_t* offsets, const double* coefs, int C,
                int groups, double* out, float* alt, const int64_t* alt_off, const SplitArgs& sp) {
     constexpr int WPB = waves_per_block<OutT>();
     const dim3 block(64 * WPB);
+    if (sp.queue) {
+        // ragged batch: as many waves as the chip runs two per SIMD, pulling units longest first
+        const char* qw = getenv("F2CNN_K1_QWAVES");
+        const int waves = std::min(units, qw ? atoi(qw) : 1024);
+        hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true, 3>), dim3((unsigned)((waves + WPB - 1) / WPB)), block, 0, st,
+                           (const WaveT*)wave, offsets, coefs, C, groups, units, out, alt, alt_off, sp);
+        return;
+    }
     if (sp.K > 1) {
         // time-split path (a2zero only): pass 1 leaves the zero-state end states, pass 2 chains them and stores
         constexpr int WPB2 = waves_per_block<OutT, 2>();
@@ -368,7 +401,7 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
     // the coefficient rows of this call are mirrored on the host by f2_upload_coefs
     bool a2zero = ctx->coefs_host.size() == (size_t)C * 10;
     for (int c = 0; a2zero && c < C; ++c) a2zero = ctx->coefs_host[(size_t)c * 10 + 5] == 0.0;
-    SplitArgs sp = {1, 0, nullptr, nullptr};
+    SplitArgs sp = {1, 0, nullptr, nullptr, nullptr, nullptr};
     if (a2zero) {
         int64_t nmax = 0;
         for (int b = 0; b < B; ++b) nmax = std::max(nmax, h_offsets[b + 1] - h_offsets[b]);
@@ -392,6 +425,28 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
             sp.mtab = (const double*)ctx->k1_mtab.ptr;
         } else {
             sp.K = 1;
+            // lengths that differ a lot: hand the units out longest first instead of one fixed unit per wave
+            int64_t total = 0;
+            for (int b = 0; b < B; ++b) total += h_offsets[b + 1] - h_offsets[b];
+            const char* env = getenv("F2CNN_K1_QUEUE");
+            const bool want = env ? atoi(env) != 0 : (units > 1024 && (double)nmax * B > 1.2 * (double)total);
+            if (want) {
+                std::vector<int> order((size_t)units + 1);
+                std::vector<int> by_len((size_t)B);
+                for (int b = 0; b < B; ++b) by_len[(size_t)b] = b;
+                std::stable_sort(by_len.begin(), by_len.end(), [&](int x, int y) {
+                    return h_offsets[x + 1] - h_offsets[x] > h_offsets[y + 1] - h_offsets[y];
+                });
+                for (int i = 0; i < B; ++i)
+                    for (int g = 0; g < groups; ++g) order[(size_t)i * groups + g] = by_len[(size_t)i] * groups + g;
+                order[(size_t)units] = 0;     // the queue counter
+                F2_TRY(f2_reserve(ctx, ctx->k1_order, sizeof(int) * order.size()));
+                F2_HIP(ctx, hipMemcpyAsync(ctx->k1_order.ptr, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice,
+                                           ctx->stream));
+                F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `order` is a local
+                sp.order = (const int*)ctx->k1_order.ptr;
+                sp.queue = (int*)ctx->k1_order.ptr + units;
+            }
         }
     }
     F2_TRY(f2_prof_begin(ctx, F2_K_FILTERBANK));

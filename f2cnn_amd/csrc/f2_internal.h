@@ -35,9 +35,12 @@ struct f2_ctx {
     f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
     f2_scratch tw_large[2][24];   // same for the global-memory transform of long rows
     f2_scratch tw_split[24];      // tables of the four-step transform (f2_envelope_split.hip), by log2 H
+    f2_scratch tw_pair;           // tables of the two-sub-row transform of 32769..65536-sample rows (f2_envelope_pair.hip)
     f2_scratch work3;             // utterance lists of the four-step launches
     f2_scratch handoff, handoff_off;   // float32 hand-off of long rows (f2_plan_handoff)
+    std::vector<int64_t> handoff_off_host;
     f2_scratch k1_states, k1_mtab;     // time-split filterbank (small batches): segment end states, T^L per channel
+    f2_scratch k1_order;               // ragged batches: unit order (longest first) + the queue counter
     int k1_mtab_L = 0;                 // segment length k1_mtab was built for ...
     std::vector<double> k1_mtab_coefs; // ... and the coefficient rows
     std::vector<int64_t> offsets_host;  // what ctx->offsets currently holds (skip re-upload when equal)
@@ -101,6 +104,11 @@ bool f2_envelope_split_supports(int log2h, int precision);
 int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets, const int* utts,
                              int nutt, int log2h, int C, int lpf, double b0, double a1, const float* d_x32,
                              const int64_t* d_x32_off);
+// rows of 32769..65536 samples, float transforms, input not aliased with the output: two LDS-resident sub-rows per workgroup
+bool f2_envelope_pair_supports(int log2h, int precision);
+int f2_launch_envelope_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets,
+                            const int64_t* h_offsets, const int* utts, int nutt, int C, int lpf, double b0, double a1,
+                            const float* d_x32, const int64_t* d_x32_off, const int64_t* h_x32_off);
 #define F2_MAX_LOG2M_LARGE 22
 int f2_launch_envelope_large(f2_ctx* ctx, const double* d_x, double* d_y, int64_t n, int C, int lpf, double b0,
                              double a1, int precision);
@@ -120,6 +128,7 @@ struct f2_handoff {
     bool f32 = false;
     float* d_x32 = nullptr;                 // scratch of the long rows, or NULL when there are none
     const int64_t* d_x32_off = nullptr;     // device, per utterance: float offset into d_x32, -1 = in the row's own slot
+    const int64_t* h_x32_off = nullptr;     // the same on the host (owned by the context, valid until the next plan)
 };
 int f2_plan_handoff(f2_ctx* ctx, const int64_t* h_offsets, int B, int C, int precision, bool want_gfb, f2_handoff* plan);
 int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,

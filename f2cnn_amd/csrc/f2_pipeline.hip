@@ -152,10 +152,14 @@ int f2_eval_utterance(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave
         F2_HIP(ctx, hipMemcpyAsync(ctx->stage_in.ptr, wave, wb, hipMemcpyHostToDevice, ctx->stream));
         d_wave = ctx->stage_in.ptr;
     }
+    // same hand-off between the two kernels as f2_eval_batch / f2_filterbank_envelope_fused take for this length, so
+    // that one utterance evaluated alone and inside a batch goes through the same envelope kernel
+    f2_handoff handoff;
+    F2_TRY(f2_plan_handoff(ctx, offsets, 1, C, fft_precision, false, &handoff));
     F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
-                                (const double*)ctx->coefs.ptr, 1, C, d_env));
+                                (const double*)ctx->coefs.ptr, 1, C, d_env, &handoff));
     F2_TRY(f2_launch_envelope(ctx, d_env, (const int64_t*)ctx->offsets.ptr, offsets, 1, C, lpf, cutoff_hz, fft_precision,
-                              d_env));
+                              d_env, &handoff));
     if (mem_space == F2_MEM_HOST && env_or_null)
         F2_HIP(ctx, hipMemcpyAsync(env_or_null, d_env, env_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (nb <= 0) {

@@ -123,3 +123,50 @@ def test_bad_arguments():
         EE.ExtractEnvelopeFromMatrix(np.ones((2, 10)), True, 9000)
     with pytest.raises(ValueError):
         EE.ExtractEnvelopeFromMatrix(np.ones(10))
+
+
+@pytest.mark.parametrize("n", [32769, 40000, 48001, 65535, 65536])
+def test_rows_of_32769_to_65536_samples_on_chip_and_four_step(n):
+    """Rows of 2-4 s stay on the chip (two LDS-resident sub-rows per workgroup, f2_envelope_pair.hip) unless the call is
+    in place on float64 rows, which keeps the four-step path: both against the oracle, and against each other."""
+    import os
+    ctx = _lib.default_context()
+    C = 5
+    m = np.random.default_rng(n).standard_normal((C, n)) * np.array([[1.0], [3000.0], [1e-3], [40.0], [7.0]])
+    off = np.array([0, n], dtype=np.int64)
+    d_in, d_out = ctx.malloc(m.nbytes), ctx.malloc(m.nbytes)
+    for lpf, cutoff in ((False, 50.0), (True, 50.0), (True, 5.0)):
+        ref = orc.extract_envelope_from_matrix(m, lpf, cutoff)
+        got = np.empty_like(m)
+        ctx.h2d(d_in, m)
+        ctx.envelope_batch(d_in, off, 1, C, lpf, cutoff, _lib.FFT_F32, d_out, _lib.MEM_DEVICE)     # on chip (float64 rows)
+        ctx.d2h(got, d_out)
+        assert chan_relerr(got, ref) <= TOL, (n, lpf, cutoff)
+        ctx.envelope_batch(d_in, off, 1, C, lpf, cutoff, _lib.FFT_F32, d_in, _lib.MEM_DEVICE)      # in place: four-step
+        four = np.empty_like(m)
+        ctx.d2h(four, d_in)
+        assert chan_relerr(four, ref) <= TOL, (n, lpf, cutoff)
+        assert chan_relerr(got, four) <= 4e-6
+    ctx.free(d_in)
+    ctx.free(d_out)
+    # through the fused call (float32 hand-off rows in the scratch buffer), with and without the on-chip kernel
+    from f2cnn_amd.gammatone import filters
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 8, 100))
+    waves = [orc.synth_utterance(n + k, n - 2 * k) for k in range(3)]      # even and odd lengths, odd scratch offsets
+    offs = np.concatenate([[0], np.cumsum([len(w) for w in waves])]).astype(np.int64)
+    flat = np.concatenate(waves)
+    env = np.empty(8 * int(offs[-1]))
+    outs = {}
+    for tag in ("pair", "four"):
+        if tag == "four":
+            os.environ["F2CNN_NO_PAIR"] = "1"
+        try:
+            ctx.filterbank_envelope_fused(flat, _lib.WAVE_I16, offs, coefs, 3, 8, True, 50.0, _lib.FFT_F32, env, None,
+                                          _lib.MEM_HOST)
+        finally:
+            os.environ.pop("F2CNN_NO_PAIR", None)
+        outs[tag] = [env[8 * offs[b]:8 * offs[b + 1]].reshape(8, -1).copy() for b in range(3)]
+    for b, w in enumerate(waves):
+        ref = orc.filter_and_envelope(w, coefs, True, 50)
+        assert chan_relerr(outs["pair"][b], ref) <= TOL and chan_relerr(outs["four"][b], ref) <= TOL
+        assert chan_relerr(outs["pair"][b], outs["four"][b]) <= 4e-6

@@ -108,3 +108,24 @@ def test_time_split_path_for_small_batches(C):
     noisy = [w.astype(np.float64) + rng.standard_normal(len(w)) for w in waves[:4]]
     for g, w in zip(_fb(noisy, coefs, "4"), noisy):
         assert chan_relerr(g, orc.erb_filterbank(w, coefs)) <= 1e-9
+
+
+def test_queue_mode_for_ragged_batches():
+    """Ragged batches hand their (utterance, channel group) units out longest first (F2CNN_K1_QUEUE=1 forces the
+    path that large ragged batches take by themselves): same bits as one fixed unit per wave."""
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    rng = np.random.default_rng(11)
+    waves = [orc.synth_utterance(100 + i, int(n)) for i, n in enumerate(rng.integers(40, 3000, size=37))]
+    waves.append(np.zeros(0, np.int16))
+    os.environ["F2CNN_K1_SPLIT"] = "0"
+    try:
+        plain = filters.erb_filterbank_batch(waves, coefs)
+        os.environ["F2CNN_K1_QUEUE"] = "1"
+        queued = filters.erb_filterbank_batch(waves, coefs)
+    finally:
+        os.environ.pop("F2CNN_K1_QUEUE", None)
+        del os.environ["F2CNN_K1_SPLIT"]
+    for a, b, w in zip(plain, queued, waves):
+        assert a.shape == b.shape == (128, len(w))
+        np.testing.assert_array_equal(a, b)
+    assert chan_relerr(queued[3], orc.erb_filterbank(waves[3], coefs)) <= 1e-9

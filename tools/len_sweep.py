@@ -3,6 +3,10 @@ Diagnostic: shows where rows leave the LDS-resident kernel (> 32768 samples) for
 import sys
 import numpy as np
 sys.path.insert(0, "/root/repo")
+import os
+if os.environ.get("F2CNN_PROBE_LIB"):
+    from f2cnn_amd import build
+    build.LIB_PATH = os.path.abspath(os.environ["F2CNN_PROBE_LIB"])
 from f2cnn_amd import _lib
 from f2cnn_amd.gammatone import filters
 import bench
