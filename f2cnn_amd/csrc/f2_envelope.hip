@@ -118,7 +118,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
 #pragma unroll
                     for (int j = 0; j < R0; ++j) {
                         const int i0 = 2 * (bf + j * NB0);
-                        const float2 t = *reinterpret_cast<const float2*>(xf + min(i0, n - 2));
+                        const f2_f2 t = load_pair_f32(xf + min(i0, n - 2));
                         v[i * R0 + j] = {i0 < n ? (F)t.x : F(0), i0 < n ? (F)t.y : F(0)};
                     }
                 }
@@ -153,7 +153,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
 #pragma unroll
                 for (int j = 0; j < R0; ++j) {
                     const int i0 = 2 * (bf + j * NB0);
-                    const double2 t = *reinterpret_cast<const double2*>(x + min(i0, n - 2));
+                    const f2_d2 t = load_pair_f64(x + min(i0, n - 2));
                     const F a = i0 < n ? (F)t.x : F(0), bb = i0 < n ? (F)t.y : F(0);
                     v[i * R0 + j] = {a, bb};
                     if constexpr (KEEP_X) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
                     for (int j = 0; j < R0; ++j) {
                         const int i0 = 2 * (bf + j * NB0);
                         const cpx<F> e = v[i * R0 + brev<R0>(j)];
-                        if (i0 < n) *reinterpret_cast<double2*>(y + i0) = make_double2((double)e.re, (double)e.im);
+                        if (i0 < n) store_pair(y + i0, (double)e.re, (double)e.im);
                     }
                 }
             }

@@ -96,6 +96,34 @@ constexpr int brev(int k) {
     return r;
 }
 
+// 16-byte store of two consecutive float64 results, non-temporal: the envelopes are written once and not read again by
+// this kernel, and keeping them out of the way of the cache's other lines is worth 4-5 % of K2 (6.14 -> 5.85 ms together
+// with non-temporal loads of the hand-off; -DF2_TEMPORAL restores plain accesses).
+typedef double f2_d2 __attribute__((ext_vector_type(2)));
+typedef float f2_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_pair(double* p, double a, double b) {
+    f2_d2 v = {a, b};
+#ifdef F2_TEMPORAL
+    *reinterpret_cast<f2_d2*>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<f2_d2*>(p));
+#endif
+}
+__device__ __forceinline__ f2_d2 load_pair_f64(const double* p) {
+#ifdef F2_TEMPORAL
+    return *reinterpret_cast<const f2_d2*>(p);
+#else
+    return __builtin_nontemporal_load(reinterpret_cast<const f2_d2*>(p));
+#endif
+}
+__device__ __forceinline__ f2_f2 load_pair_f32(const float* p) {
+#ifdef F2_TEMPORAL
+    return *reinterpret_cast<const f2_f2*>(p);
+#else
+    return __builtin_nontemporal_load(reinterpret_cast<const f2_f2*>(p));
+#endif
+}
+
 __device__ __forceinline__ double shfl_up_f64(double v, int d) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __shfl_up(lo, d);
@@ -244,7 +272,7 @@ __device__ __forceinline__ double lowpass_pairs_store(const F (&er)[NBLK], const
         const F y1 = qf * y0 + u1[jj];
         const int i0 = 2 * (tid + NT * jj);
         if (pairs_ok) {
-            if (i0 < n) *reinterpret_cast<double2*>(y + i0) = make_double2((double)y0, (double)y1);
+            if (i0 < n) store_pair(y + i0, (double)y0, (double)y1);
         } else {
             if (i0 < n) y[i0] = (double)y0;
             if (i0 + 1 < n) y[i0 + 1] = (double)y1;
