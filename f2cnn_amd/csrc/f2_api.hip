@@ -145,7 +145,8 @@ int f2_ctx_destroy(f2_ctx* ctx) {
             if (s.ptr) (void)hipFree(s.ptr);
     for (f2_scratch& s : ctx->tw_split)
         if (s.ptr) (void)hipFree(s.ptr);
-    if (ctx->tw_pair.ptr) (void)hipFree(ctx->tw_pair.ptr);
+    for (f2_scratch* sc : {&ctx->tw_pair[0], &ctx->tw_pair[1], &ctx->pair_list[0], &ctx->pair_list[1]})
+        if (sc->ptr) (void)hipFree(sc->ptr);
     if (ctx->work3.ptr) (void)hipFree(ctx->work3.ptr);
     if (ctx->k1_states.ptr) (void)hipFree(ctx->k1_states.ptr);
     if (ctx->k1_mtab.ptr) (void)hipFree(ctx->k1_mtab.ptr);
@@ -367,15 +368,18 @@ int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C) {
 int f2_plan_handoff(f2_ctx* ctx, const int64_t* h_offsets, int B, int C, int precision, bool want_gfb, f2_handoff* plan) {
     *plan = f2_handoff();
     if (want_gfb || precision != F2_FFT_F32) return F2_OK;
-    constexpr size_t SCRATCH_LIMIT = size_t(24) << 30;
+    constexpr size_t SCRATCH_LIMIT = size_t(64) << 30;
     std::vector<int64_t> off((size_t)B, -1);
     int64_t floats = 0;
     bool any_long = false;
     for (int b = 0; b < B; ++b) {
         const int64_t n = h_offsets[b + 1] - h_offsets[b];
-        if (n <= (int64_t(2) << 14)) continue;                          // LDS-resident kernels: in the row's own slot
+        // rows of the single-row LDS-resident kernels hand over inside their own output slot; the two-sub-row kernel
+        // (32769..65536 samples) and the four-step path read compact scratch rows
+        if (n <= (int64_t(1) << 15)) continue;
         const int log2h = f2_log2_ceil(n) - 1;
-        if (!f2_envelope_split_supports(log2h, precision)) return F2_OK;   // a row for the general path: float64 for all
+        if (!f2_envelope_pair_supports(log2h, precision) && !f2_envelope_split_supports(log2h, precision))
+            return F2_OK;   // a row for the general path: float64 for all
         off[(size_t)b] = floats;
         floats += (int64_t)C * n;
         any_long = true;

@@ -476,7 +476,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
 
     // group the utterances by padded length (one kernel instantiation per FFT size)
     std::vector<std::vector<int>> groups(32), split_groups(32);
-    std::vector<int> pair_group;   // 32769..65536 samples, on-chip (f2_envelope_pair.hip)
+    std::vector<int> pair_group[2];   // [1]: 32769..65536 samples, two sub-rows per workgroup (f2_envelope_pair.hip)
     const bool pair_ok = !getenv("F2CNN_NO_PAIR") && ((f32_in && handoff->d_x32) || (!f32_in && d_gfb != d_env));
     int n_large = 0;
     for (int b = 0; b < B; ++b) {
@@ -485,8 +485,8 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         const int log2m = n <= 2 ? 1 : f2_log2_ceil(n);
         const int log2h = log2m - 1;
         const int maxl = precision == F2_FFT_F32 ? MAX_LOG2H_F32 : MAX_LOG2H_F64;
-        if (log2h > maxl && pair_ok && f2_envelope_pair_supports(log2h, precision)) {
-            pair_group.push_back(b);
+        if (pair_ok && f2_envelope_pair_supports(log2h, precision) && (!f32_in || (handoff->h_x32_off && handoff->h_x32_off[b] >= 0))) {
+            pair_group[log2h - 14].push_back(b);
             ++n_large;
             continue;
         }
@@ -508,10 +508,12 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         }
         groups[log2h].push_back(b);
     }
-    if (!pair_group.empty())
-        F2_TRY(f2_launch_envelope_pair(ctx, d_gfb, d_env, d_offsets, h_offsets, pair_group.data(), (int)pair_group.size(), C,
-                                       P.lpf, P.b0, P.a1, f32_in ? handoff->d_x32 : nullptr,
-                                       f32_in ? handoff->d_x32_off : nullptr, f32_in ? handoff->h_x32_off : nullptr));
+    for (int g = 0; g < 2; ++g)
+        if (!pair_group[g].empty())
+            F2_TRY(f2_launch_envelope_pair(ctx, d_gfb, d_env, d_offsets, h_offsets, pair_group[g].data(),
+                                           (int)pair_group[g].size(), 14 + g, C, P.lpf, P.b0, P.a1,
+                                           f32_in ? handoff->d_x32 : nullptr, f32_in ? handoff->d_x32_off : nullptr,
+                                           f32_in ? handoff->h_x32_off : nullptr));
     for (int log2h = 0; log2h < 32; ++log2h)
         if (!split_groups[log2h].empty())
             F2_TRY(f2_launch_envelope_split(ctx, d_gfb, d_env, d_offsets, split_groups[log2h].data(),

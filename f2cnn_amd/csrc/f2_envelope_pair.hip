@@ -27,17 +27,21 @@ using namespace f2fft;
 
 namespace {
 
-constexpr int LOG2S = 14;
-constexpr int HS = 1 << LOG2S;
-constexpr int NT = 1024;
-constexpr int PT = plan_points_per_thread(LOG2S, NT);
-constexpr int R0 = 1 << plan_bits(LOG2S, 0);
-constexpr int NB0 = HS / R0;
+// Sub-row geometry: LOG2S = 14 (rows of 32769..65536 samples, 1024 threads, one workgroup per CU); the kernel is generic
+// in it (13: 512 threads, two workgroups per CU - measured slower than the single-row plan, see below).
+template <int LOG2S>
+struct Geo {
+    static constexpr int HS = 1 << LOG2S;
+    static constexpr int NT = threads_for<float, LOG2S>();
+    static constexpr int PT = plan_points_per_thread(LOG2S, NT);
+    static constexpr int R0 = 1 << plan_bits(LOG2S, 0);
+    static constexpr int NB0 = HS / R0;
+    static_assert(PT == R0 && NB0 == NT, "one radix-16 butterfly per thread in the first and last pass");
+};
 #ifndef F2_PAIR_LOADCHUNK
 #define F2_PAIR_LOADCHUNK 8
 #endif
 constexpr int LOADCHUNK = F2_PAIR_LOADCHUNK;   // points whose loads are in flight together in the two radix-2 stages
-static_assert(PT == R0 && NB0 == NT, "one radix-16 butterfly per thread in the first and last pass");
 
 struct PairParams {
     const double* gfb;
@@ -68,9 +72,10 @@ __device__ __forceinline__ cpx<float> load_pair(const T* __restrict__ x, int n, 
 }
 
 // forward transform of the sub-row in v, Hilbert pair step in LDS, second transform back into v
-template <bool ODD>
+template <int LOG2S, bool ODD>
 __device__ __forceinline__ void sub_row(cpx<float>* lds, const cpx<float>* __restrict__ tw, const cpx<float>* twl,
-                                        const cpx<float>* __restrict__ vo, int tid, cpx<float> (&v)[PT]) {
+                                        const cpx<float>* __restrict__ vo, int tid, cpx<float> (&v)[Geo<LOG2S>::PT]) {
+    constexpr int HS = Geo<LOG2S>::HS, NT = Geo<LOG2S>::NT, PT = Geo<LOG2S>::PT;
     constexpr bool T0R = derive_tw0<float, LOG2S>();
     fft_all<float, LOG2S, false, PT, NT, T0R>(lds, tw, twl, tid, v);       // spectrum at lds[cpad(k)]
     const float sc = 1.0f / (float)HS;
@@ -123,8 +128,9 @@ __device__ __forceinline__ void sub_row(cpx<float>* lds, const cpx<float>* __res
 
 // T: float (the filterbank's compact float32 hand-off rows) or double (a float64 filterbank matrix); EVEN: every row of
 // the launch has an even length and starts on a 2-element boundary, so a pair is one load (the host groups the utterances).
-template <typename T, bool EVEN>
-__global__ __launch_bounds__(NT, 4) void k_envelope_pair(PairParams P, const cpx<float>* __restrict__ tw) {
+template <int LOG2S, typename T, bool EVEN>
+__global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParams P, const cpx<float>* __restrict__ tw) {
+    constexpr int HS = Geo<LOG2S>::HS, NT = Geo<LOG2S>::NT, PT = Geo<LOG2S>::PT, R0 = Geo<LOG2S>::R0, NB0 = Geo<LOG2S>::NB0;
     constexpr int CS = cpad_size(HS);
     constexpr int TWL = plan_tw_lds_count(LOG2S);
     constexpr size_t LP = lowpass_lds_bytes<float, NT, R0>();
@@ -165,12 +171,12 @@ __global__ __launch_bounds__(NT, 4) void k_envelope_pair(PairParams P, const cpx
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    sub_row<false>(lds, tw, twl, P.vo, tid, v);
+    sub_row<LOG2S, false>(lds, tw, twl, P.vo, tid, v);
 #pragma unroll
     for (int j = 0; j < R0; ++j) park_e[tid + j * NB0] = v[brev<R0>(j)];
 #pragma unroll
     for (int j = 0; j < R0; ++j) v[j] = park_b[tid + j * NB0];       // this thread's own stores: no synchronisation
-    sub_row<true>(lds, tw, twl, P.vo, tid, v);
+    sub_row<LOG2S, true>(lds, tw, twl, P.vo, tid, v);
 
     // last radix-2 stage + magnitude: lower half of the row from E + T O, upper half from E - T O. The lower half's
     // envelopes stay in registers until every thread has read its parked points (they overwrite the parking area);
@@ -232,8 +238,10 @@ __global__ __launch_bounds__(NT, 4) void k_envelope_pair(PairParams P, const cpx
                                        ycarry, *e_mid_p);
 }
 
-int ensure_pair_tables(f2_ctx* ctx) {
-    if (ctx->tw_pair.ptr) return F2_OK;
+template <int LOG2S>
+int ensure_pair_tables(f2_ctx* ctx, f2_scratch& slot) {
+    constexpr int HS = Geo<LOG2S>::HS;
+    if (slot.ptr) return F2_OK;
     const long double pi = 3.14159265358979323846264338327950288L;
     std::vector<cpx<float>> host((size_t)HS + HS / 2);
     for (int m = 0; m < HS; ++m) {
@@ -244,43 +252,36 @@ int ensure_pair_tables(f2_ctx* ctx) {
         const long double ang = pi * (long double)(2 * j + 1) / (long double)(2 * HS);
         host[(size_t)HS + j] = {(float)cosl(ang), (float)(-sinl(ang))};
     }
-    F2_TRY(f2_reserve(ctx, ctx->tw_pair, sizeof(cpx<float>) * host.size()));
-    F2_HIP(ctx, hipMemcpyAsync(ctx->tw_pair.ptr, host.data(), sizeof(cpx<float>) * host.size(), hipMemcpyHostToDevice, ctx->stream));
+    F2_TRY(f2_reserve(ctx, slot, sizeof(cpx<float>) * host.size()));
+    F2_HIP(ctx, hipMemcpyAsync(slot.ptr, host.data(), sizeof(cpx<float>) * host.size(), hipMemcpyHostToDevice, ctx->stream));
     F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return F2_OK;
 }
 
-}  // namespace
-
-// Rows of 2^15 complex points (32768 < n <= 65536), float transforms, input not aliased with the output rows.
-bool f2_envelope_pair_supports(int log2h, int precision) { return precision == F2_FFT_F32 && log2h == LOG2S + 1; }
-
-int f2_launch_envelope_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets,
-                            const int64_t* h_offsets, const int* utts, int nutt, int C, int lpf, double b0, double a1,
-                            const float* d_x32, const int64_t* d_x32_off, const int64_t* h_x32_off) {
-    if (nutt <= 0) return F2_OK;
-    F2_CHECK(ctx, d_x32 || d_gfb != d_env, F2_ERR_INVALID, "the on-chip path for 32769..65536-sample rows cannot run in place");
-    F2_TRY(ensure_pair_tables(ctx));
+template <int LOG2S>
+int launch_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets, const int64_t* h_offsets,
+                const int* utts, int nutt, int C, int lpf, double b0, double a1, const float* d_x32,
+                const int64_t* d_x32_off, const int64_t* h_x32_off) {
+    constexpr int HS = Geo<LOG2S>::HS, NT = Geo<LOG2S>::NT;
+    f2_scratch& tables = ctx->tw_pair[LOG2S - 13];
+    F2_TRY(ensure_pair_tables<LOG2S>(ctx, tables));
     F2_TRY(ensure_twiddles<float>(ctx, LOG2S, ctx->tw[0][LOG2S]));
     // utterances whose rows all have an even length and start on an even element first: their pairs are single loads
-    std::vector<int> order;
-    order.reserve((size_t)nutt);
-    for (int pass = 0; pass < 2; ++pass)
-        for (int i = 0; i < nutt; ++i) {
-            const int b = utts[i];
-            const int64_t n = h_offsets[b + 1] - h_offsets[b];
-            const int64_t base = d_x32 ? h_x32_off[b] : (int64_t)C * h_offsets[b];
-            const bool even = (n % 2 == 0) && (base % 2 == 0);
-            if (even == (pass == 0)) order.push_back(b);
-        }
-    int n_even = 0;
-    for (int b : order) {
+    auto is_even = [&](int b) {
         const int64_t n = h_offsets[b + 1] - h_offsets[b];
         const int64_t base = d_x32 ? h_x32_off[b] : (int64_t)C * h_offsets[b];
-        if ((n % 2 == 0) && (base % 2 == 0)) ++n_even;
-    }
-    F2_TRY(f2_reserve(ctx, ctx->work3, sizeof(int) * (size_t)nutt));
-    F2_HIP(ctx, hipMemcpyAsync(ctx->work3.ptr, order.data(), sizeof(int) * (size_t)nutt, hipMemcpyHostToDevice, ctx->stream));
+        return (n % 2 == 0) && (base % 2 == 0);
+    };
+    std::vector<int> order;
+    order.reserve((size_t)nutt);
+    for (int i = 0; i < nutt; ++i)
+        if (is_even(utts[i])) order.push_back(utts[i]);
+    const int n_even = (int)order.size();
+    for (int i = 0; i < nutt; ++i)
+        if (!is_even(utts[i])) order.push_back(utts[i]);
+    f2_scratch& list = ctx->pair_list[LOG2S - 13];
+    F2_TRY(f2_reserve(ctx, list, sizeof(int) * (size_t)nutt));
+    F2_HIP(ctx, hipMemcpyAsync(list.ptr, order.data(), sizeof(int) * (size_t)nutt, hipMemcpyHostToDevice, ctx->stream));
     F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `order` is a local
     PairParams P;
     P.gfb = d_gfb;
@@ -293,25 +294,43 @@ int f2_launch_envelope_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, con
     P.a1 = a1;
     P.x32 = d_x32;
     P.x32_off = d_x32_off;
-    P.tx = (const cpx<float>*)ctx->tw_pair.ptr;
+    P.tx = (const cpx<float>*)tables.ptr;
     P.vo = P.tx + HS;
     for (int even = 0; even < 2; ++even) {
         const int cnt = even ? n_even : nutt - n_even;
         if (cnt == 0) continue;
-        P.ulist = (const int*)ctx->work3.ptr + (even ? 0 : n_even);
+        P.ulist = (const int*)list.ptr + (even ? 0 : n_even);
         const dim3 grid((unsigned)((size_t)cnt * C)), block(NT);
         const cpx<float>* tw = (const cpx<float>*)ctx->tw[0][LOG2S].ptr;
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
         if (d_x32 && even)
-            hipLaunchKernelGGL((k_envelope_pair<float, true>), grid, block, 0, ctx->stream, P, tw);
+            hipLaunchKernelGGL((k_envelope_pair<LOG2S, float, true>), grid, block, 0, ctx->stream, P, tw);
         else if (d_x32)
-            hipLaunchKernelGGL((k_envelope_pair<float, false>), grid, block, 0, ctx->stream, P, tw);
+            hipLaunchKernelGGL((k_envelope_pair<LOG2S, float, false>), grid, block, 0, ctx->stream, P, tw);
         else if (even)
-            hipLaunchKernelGGL((k_envelope_pair<double, true>), grid, block, 0, ctx->stream, P, tw);
+            hipLaunchKernelGGL((k_envelope_pair<LOG2S, double, true>), grid, block, 0, ctx->stream, P, tw);
         else
-            hipLaunchKernelGGL((k_envelope_pair<double, false>), grid, block, 0, ctx->stream, P, tw);
+            hipLaunchKernelGGL((k_envelope_pair<LOG2S, double, false>), grid, block, 0, ctx->stream, P, tw);
         F2_HIP(ctx, hipGetLastError());
         F2_TRY(f2_prof_end(ctx, F2_K_ENVELOPE));
     }
     return F2_OK;
+}
+
+}  // namespace
+
+// Rows of 2^15 complex points (32768 < n <= 65536), float transforms, input not aliased with the output rows. (The same
+// kernel with 8192-point sub-rows, two workgroups per CU, was measured for 16385..32768-sample rows: 12.2 ms against the
+// single-row 1024-thread plan's 8.0 ms for 16 M samples - the parking and the extra stages cost more than the second
+// workgroup buys - so those rows stay with f2_envelope.hip.)
+bool f2_envelope_pair_supports(int log2h, int precision) { return precision == F2_FFT_F32 && log2h == 15; }
+
+// All utterances `utts` have the same transform size 2^log2h complex points.
+int f2_launch_envelope_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets,
+                            const int64_t* h_offsets, const int* utts, int nutt, int log2h, int C, int lpf, double b0,
+                            double a1, const float* d_x32, const int64_t* d_x32_off, const int64_t* h_x32_off) {
+    if (nutt <= 0) return F2_OK;
+    F2_CHECK(ctx, d_x32 || d_gfb != d_env, F2_ERR_INVALID, "the two-sub-row envelope path cannot run in place");
+    F2_CHECK(ctx, f2_envelope_pair_supports(log2h, F2_FFT_F32), F2_ERR_INVALID, "unsupported size 2^%d", log2h);
+    return launch_pair<14>(ctx, d_gfb, d_env, d_offsets, h_offsets, utts, nutt, C, lpf, b0, a1, d_x32, d_x32_off, h_x32_off);
 }

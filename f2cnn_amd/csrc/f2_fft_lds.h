@@ -34,8 +34,11 @@ constexpr bool derive_tw0() { return sizeof(F) == 4 && LOG2H >= 11 && LOG2H <= 1
 
 // Whether the Hilbert pair step is folded into the inverse transform's first pass (needs ~3x the pass's points in
 // registers for a moment: only where the register budget allows) or runs as its own sweep over LDS.
+#ifndef F2_FUSE_HILBERT_MAX
+#define F2_FUSE_HILBERT_MAX 12
+#endif
 template <typename F, int LOG2H>
-constexpr bool fuse_hilbert() { return LOG2H >= 1 && LOG2H <= 12 && sizeof(F) == 4; }
+constexpr bool fuse_hilbert() { return LOG2H >= 1 && LOG2H <= F2_FUSE_HILBERT_MAX && sizeof(F) == 4; }
 
 // ---- radix plan: symmetric (first radix == last radix), radices 2..32 ----
 // H = 8192 (the 1 s / 16 kHz row) runs as 16-8-4-16 on 512 threads: 16 points per thread in every pass keeps
