@@ -6,6 +6,8 @@ package implements:
     python -m f2cnn_amd prepare label                       (needs the VTR .FB and TIMIT .PHN side files)
     python -m f2cnn_amd prepare input [--cutoff HZ] [--label/-l CSV] [--input/-i NPY]
     python -m f2cnn_amd prepare features [--cutoff HZ]     (filter + envelope in one pass, not in the reference)
+    (filter / envelope / features also take --skip-existing to resume and --metrics FILE for a JSON summary; a file that
+     cannot be read is reported and skipped, the exit status is then 2)
     python -m f2cnn_amd cnn train [--input/-i NPY] [--label/-l CSV]   (PyTorch-ROCm autograd; weights -> last_trained_model)
     python -m f2cnn_amd cnn eval --file/-f WAV [--lpf HZ] [--model/-m NPZ]
     python -m f2cnn_amd cnn evalnoise --file/-f WAV --noise/-n SNRdB [--lpf HZ] [--model/-m NPZ]
@@ -31,6 +33,10 @@ def build_parser():
     p.add_argument('--file', '-f', dest='file', nargs='?')
     p.add_argument('--input', '-i', dest='inputFile', nargs='?')
     p.add_argument('--label', '-l', dest='labelFile', nargs='?')
+    p.add_argument('--skip-existing', action='store_true',
+                   help="filter / envelope / features: leave files whose outputs are already up to date (resume)")
+    p.add_argument('--metrics', dest='metrics', nargs='?',
+                   help="filter / envelope / features: write files, audio seconds, wall time and audio-s/s as JSON")
     c = sub.add_parser('cnn', help='CNN commands')
     c.add_argument('--file', '-f', dest='file', nargs='?')
     c.add_argument('--input', '-i', dest='inputFile', nargs='?')
@@ -55,6 +61,9 @@ def main(argv=None):
                 kwargs['labelFile'] = args.labelFile
             if args.inputFile is not None:
                 kwargs['inputFile'] = args.inputFile
+        if args.prepare_command in ('filter', 'envelope', 'features'):
+            kwargs['skip_existing'] = args.skip_existing
+            kwargs['metrics'] = args.metrics
         if args.prepare_command == 'filter':
             from .scripts.processing.GammatoneFiltering import FilterAllOrganisedFiles as fn
         elif args.prepare_command == 'envelope':
@@ -65,7 +74,9 @@ def main(argv=None):
             from .scripts.processing.EnvelopeExtraction import FilterAndExtractAll as fn
         else:
             from .scripts.processing.InputGenerator import GenerateInputData as fn
-        fn(**kwargs)
+        report = fn(**kwargs)
+        if getattr(report, "exit_status", 0):          # some files could not be processed (the others were)
+            return report.exit_status
     elif 'cnn_command' in args:
         if args.cnn_command == 'train':                        # f2cnn.py:126-143
             import os

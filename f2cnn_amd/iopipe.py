@@ -5,12 +5,98 @@ EnvelopeExtraction.py:145-149); here one process drives one GPU, so the reads of
 writes of the previous one run on threads (NumPy file I/O releases the GIL) while the GPU works on the current
 batch. Results are written by the caller's `save` exactly as the reference names and formats them.
 """
+import json as _json
 import os
 import threading
+import time as _time
 import weakref
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy
+
+
+class Unreadable:
+    """What a guarded `load` returns for an input that could not be read (the reason travels with it)."""
+
+    def __init__(self, reason):
+        self.reason = reason
+
+
+class JobReport:
+    """Bookkeeping of one file-level command (the reference only prints; here a failing file does not
+    end the run, a re-run can skip what is already done, and the totals can be written as JSON).
+
+      skip_existing   inputs whose outputs already exist and are not older than the input are left alone (resume)
+      failed          inputs that could not be read or processed: reported, skipped, and the command's exit status
+                      becomes 2 (the reference would have died in the worker, GammatoneFiltering.py:69-83)
+      metrics         path of a JSON file: command, rank/world, files, skipped, failed, audio seconds, wall seconds,
+                      audio-seconds per second
+    """
+
+    def __init__(self, command, skip_existing=False, metrics=None):
+        from .runtime import rank_world
+        self.command, self.skip_existing, self.metrics = command, bool(skip_existing), metrics
+        self.rank, self.world = rank_world()
+        self.started = _time.time()
+        self.done = self.skipped = 0
+        self.failed = []
+        self.audio_s = 0.0
+        self._lock = threading.Lock()
+
+    def pending(self, items, outputs_of):
+        """The items still to do: all of them, or with skip_existing those with a missing or stale output."""
+        if not self.skip_existing:
+            return list(items)
+        todo = []
+        for it in items:
+            outs = outputs_of(it)
+            fresh = all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(it) for o in outs)
+            if fresh:
+                self.skipped += 1
+            else:
+                todo.append(it)
+        if self.skipped:
+            print("{} of {} files are up to date and skipped.".format(self.skipped, len(items)))
+        return todo
+
+    def guard(self, load):
+        """load(item, ...) that returns Unreadable(reason) instead of raising."""
+        def guarded(item, *rest):
+            try:
+                return load(item, *rest)
+            except Exception as exc:      # a corrupt or unsupported file: the other files of the corpus still run
+                self.fail(item, exc)
+                return Unreadable(repr(exc))
+        return guarded
+
+    def fail(self, item, exc):
+        with self._lock:
+            self.failed.append((str(item), repr(exc)))
+        print("ERROR: {} skipped: {}".format(item, exc))
+
+    def add(self, samples, framerate):
+        with self._lock:
+            self.done += 1
+            self.audio_s += samples / float(framerate)
+            return self.done
+
+    def finish(self):
+        wall = _time.time() - self.started
+        out = {"command": self.command, "rank": self.rank, "world": self.world, "files": self.done,
+               "files_skipped": self.skipped, "files_failed": len(self.failed), "failed": self.failed,
+               "audio_seconds": round(self.audio_s, 3), "wall_s": round(wall, 3),
+               "audio_s_per_s": round(self.audio_s / wall, 2) if wall > 0 else None}
+        if self.metrics:
+            path = self.metrics if self.world == 1 else "{}.rank{}".format(self.metrics, self.rank)
+            with open(path, "w") as f:
+                _json.dump(out, f)
+        if self.failed:
+            print("{} file(s) could not be processed.".format(len(self.failed)))
+        return out
+
+    @property
+    def exit_status(self):
+        return 2 if self.failed else 0
 
 
 def _workers(kind):

@@ -12,7 +12,8 @@ import time
 import numpy
 
 from ... import _lib
-from ...iopipe import host_pool, npy_layout, read_npy_into, run_batches
+from ...config import F2Config
+from ...iopipe import JobReport, Unreadable, host_pool, npy_layout, read_npy_into, run_batches
 from ...runtime import shard_for_rank
 
 FFT_PRECISION = _lib.FFT_F64 if os.environ.get("F2CNN_FFT", "f32").lower() in ("f64", "double") else _lib.FFT_F32
@@ -74,9 +75,11 @@ def ExtractAndSaveEnvelope(gfbFileName, nbf=None, LPF=False, CUTOFF=100):
     SaveEnvelope(ExtractEnvelope(gfbFileName, LPF, CUTOFF), gfbFileName, nbf, 1)
 
 
-def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16):
-    """`prepare envelope`: every resources/f2cnn/*/*.GFB.npy -> .ENV1.npy (reference :125-153)."""
+def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16, skip_existing=False, metrics=None):
+    """`prepare envelope`: every resources/f2cnn/*/*.GFB.npy -> .ENV1.npy (reference :125-153). Returns the JobReport."""
     TotalTime = time.time()
+    report = JobReport("prepare envelope", skip_existing, metrics)
+    framerate = F2Config().framerate
     gfbFiles = sorted(glob.glob(os.path.join("resources", "f2cnn", "*", "*.GFB.npy")))
     if not gfbFiles:   # the reference indexes [0] first and dies with IndexError; same message, checked first
         print("ERROR: NO .GFB.npy FILES FOUND, PLEASE GENERATE FILTERED OUTPUTS")
@@ -88,8 +91,7 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16):
     else:
         print("Not using Low Pass Filtering")
     print(len(gfbFiles), ".GFB.npy files found")
-    mine = shard_for_rank(gfbFiles)
-    progress = {"done": 0}
+    mine = report.pending(shard_for_rank(gfbFiles), lambda name: [envelope_filename(name) + '.npy'])
 
     contexts = _lib.pipeline_contexts(2)     # alternate streams: one batch's copies beside the next one's kernels
     turn = [0]
@@ -97,7 +99,10 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16):
 
     def plan(chunk):
         """One pooled page-locked buffer per batch; every file is read straight into its (C, N_b) block of it."""
-        layouts = [npy_layout(name) for name in chunk]
+        try:
+            layouts = [npy_layout(name) for name in chunk]
+        except OSError:                          # an unreadable file: the general path reports it per file
+            return None, [None] * len(chunk)
         plain = all(l is not None and len(l[0]) == 2 and l[0][0] == layouts[0][0][0] for l in layouts)
         if not plain:                            # Fortran order, another dtype, mixed channel counts: general path
             return None, [None] * len(chunk)
@@ -115,6 +120,13 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16):
         return read_npy_into(name, slot[1], slot[0])
 
     def compute(loaded, state):
+        if any(isinstance(m, Unreadable) for _, m in loaded):
+            # (a planned batch with an unreadable file: the good blocks are copied out and go the general way)
+            loaded = [(n, numpy.array(m)) for n, m in loaded if not isinstance(m, Unreadable)]
+            loaded = [(n, m.reshape(state["C"], -1) if state is not None else m) for n, m in loaded]
+            state = None
+            if not loaded:
+                return []
         names = [n for n, _ in loaded]
         if state is None:
             # one launch per distinct channel count (normally one)
@@ -141,16 +153,17 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16):
 
     def save(name, e):
         numpy.save(envelope_filename(name), e)
-        progress["done"] += 1
-        print("\t{:<50} done ! {}/{} Files.".format(envelope_filename(name), progress["done"], len(mine)))
+        print("\t{:<50} done ! {}/{} Files.".format(envelope_filename(name), report.add(e.shape[1], framerate), len(mine)))
 
-    run_batches(mine, load, compute, save, batch=batch_files, plan=plan)
+    run_batches(mine, report.guard(load), compute, save, batch=batch_files, plan=plan)
     print("Extracted Envelopes from all files.")
     print('              Total time:', time.time() - TotalTime)
     print('')
+    report.finish()
+    return report
 
 
-def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True):
+def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True, skip_existing=False, metrics=None):
     """`prepare filter` followed by `prepare envelope` in ONE pass over the corpus: every
     resources/f2cnn/*/*.WAV -> <base>.GFB.npy (unless keep_gfb is False) and <base>.ENV1.npy, through
     f2_filterbank_envelope_fused. Nothing is read back from disk between the two stages (the reference writes the
@@ -159,6 +172,7 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True):
     from ...gammatone import filters
     from .GammatoneFiltering import GetArrayFromWAV, filterbank_from_config
     TotalTime = time.time()
+    report = JobReport("prepare features", skip_existing, metrics)
     wavFiles = sorted(glob.glob(os.path.join("resources", "f2cnn", "*", "*.WAV")))
     if not wavFiles:
         print("NO WAV FILES FOUND, PLEASE ORGANIZE FILES")
@@ -171,13 +185,20 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True):
     Cn = coefs.shape[0]
     contexts = _lib.pipeline_contexts(2)
     turn = [0]
-    mine = shard_for_rank(wavFiles)
-    progress = {"done": 0}
+    def outputs(name):
+        base = os.path.splitext(name)[0]
+        return [base + '.ENV' + str(METHOD) + '.npy'] + ([base + '.GFB.npy'] if keep_gfb else [])
+    mine = report.pending(shard_for_rank(wavFiles), outputs)
+    rates = {}
 
     def load(name):
-        return GetArrayFromWAV(name)[1]
+        rates[name], samples = GetArrayFromWAV(name)
+        return samples
 
     def compute(loaded):
+        loaded = [(n, w) for n, w in loaded if not isinstance(w, Unreadable)]
+        if not loaded:
+            return []
         ctx = contexts[turn[0] % len(contexts)]
         turn[0] += 1
         args = [filters._wave_args(w) for _, w in loaded]
@@ -204,10 +225,12 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True):
         if gfb is not None:
             numpy.save(base + '.GFB', gfb)
         numpy.save(base + '.ENV' + str(METHOD), env)
-        progress["done"] += 1
-        print("\t{:<50} done ! {}/{} Files.".format(base + '.ENV' + str(METHOD), progress["done"], len(mine)))
+        print("\t{:<50} done ! {}/{} Files.".format(base + '.ENV' + str(METHOD), report.add(env.shape[1], rates[name]),
+                                                     len(mine)))
 
-    run_batches(mine, load, compute, save, batch=batch_files)
+    run_batches(mine, report.guard(load), compute, save, batch=batch_files)
     print("Filtered and extracted envelopes of all files.")
     print('              Total time:', time.time() - TotalTime)
     print('')
+    report.finish()
+    return report

@@ -13,7 +13,7 @@ import numpy
 from ... import _lib
 from ...config import F2Config
 from ...gammatone import filters
-from ...iopipe import host_pool, run_batches
+from ...iopipe import JobReport, Unreadable, host_pool, run_batches
 from ...runtime import shard_for_rank
 from ...wavio import read_audio
 
@@ -56,9 +56,10 @@ def filterbank_from_config(cfg=None):
     return cf, filters.make_erb_filters(cfg.framerate, cf)
 
 
-def FilterAllOrganisedFiles(batch_files=16):
-    """`prepare filter`: every resources/f2cnn/*/*.WAV -> .GFB.npy (reference :93-128)."""
+def FilterAllOrganisedFiles(batch_files=16, skip_existing=False, metrics=None):
+    """`prepare filter`: every resources/f2cnn/*/*.WAV -> .GFB.npy (reference :93-128). Returns the JobReport."""
     TotalTime = time.time()
+    report = JobReport("prepare filter", skip_existing, metrics)
     wavFiles = sorted(glob.glob(os.path.join("resources", "f2cnn", "*", "*.WAV")))
     if not wavFiles:
         print("NO WAV FILES FOUND, PLEASE ORGANIZE FILES")
@@ -67,12 +68,13 @@ def FilterAllOrganisedFiles(batch_files=16):
         os.path.split(wavFiles[0])[0]))
     print(len(wavFiles), "files found")
     _, coefs = filterbank_from_config()
-    mine = shard_for_rank(wavFiles)
-    progress = {"done": 0}
+    mine = report.pending(shard_for_rank(wavFiles), lambda name: [os.path.splitext(name)[0] + '.GFB.npy'])
+    rates = {}
 
     def load(name):
         print("Filtering:\t{}".format(name))
-        return GetArrayFromWAV(name)[1]
+        rates[name], samples = GetArrayFromWAV(name)
+        return samples
 
     # batches alternate between two device contexts (streams): the device-to-host copy of one batch runs beside the
     # host-to-device copy and the kernel of the next, while writer threads save the batch before
@@ -80,6 +82,9 @@ def FilterAllOrganisedFiles(batch_files=16):
     turn = [0]
 
     def compute(loaded):
+        loaded = [(n, w) for n, w in loaded if not isinstance(w, Unreadable)]
+        if not loaded:
+            return []
         ctx = contexts[turn[0] % len(contexts)]
         turn[0] += 1
         names = [n for n, _ in loaded]
@@ -90,10 +95,11 @@ def FilterAllOrganisedFiles(batch_files=16):
         gfb = os.path.splitext(name)[0] + '.GFB'
         print("Saving:\t\t{}.npy".format(gfb))
         saveGFBMatrix(gfb, m)
-        progress["done"] += 1
-        print("\t\t{:<50} done ! {}/{} Files.".format(name, progress["done"], len(mine)))
+        print("\t\t{:<50} done ! {}/{} Files.".format(name, report.add(m.shape[1], rates[name]), len(mine)))
 
-    run_batches(mine, load, compute, save, batch=batch_files)
+    run_batches(mine, report.guard(load), compute, save, batch=batch_files)
     print("Filtered and Saved all files.")
     print('                Total time:', time.time() - TotalTime)
     print('')
+    report.finish()
+    return report

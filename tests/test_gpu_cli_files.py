@@ -146,3 +146,51 @@ def test_batched_eval_matches_one_at_a_time(tmp_path, monkeypatch, capsys):
     with pytest.raises(ValueError, match="sample type"):
         Evaluating.EvaluateWavArrays([waves[0], waves[1].astype(np.float64)], 16000, model=m)
     capsys.readouterr()
+
+
+def test_resume_metrics_and_unreadable_files(tmp_path, monkeypatch, capsys):
+    """`prepare filter / envelope / features` with --skip-existing and --metrics; a file that cannot be read does not
+    stop the others and turns the exit status into 2."""
+    import json
+    monkeypatch.chdir(tmp_path)
+    config.write_default()
+    os.makedirs(os.path.join("resources", "f2cnn", "TEST"))
+    names = []
+    for i, n in enumerate((3000, 16000, 40000, 2222, 5000, 1000)):
+        p = os.path.join("resources", "f2cnn", "TEST", f"DR2.F{i}.SA{i}.WAV")
+        wavio.write_sphere(p, 16000, orc.synth_utterance(700 + i, n))
+        names.append(os.path.splitext(p)[0])
+    bad = os.path.join("resources", "f2cnn", "TEST", "DR2.BAD.SA9.WAV")
+    open(bad, "wb").write(b"NIST_1A\n   1024\nsample_coding -s26 pcm,embedded-shorten-v2.00\nend_head\n".ljust(1024) + b"\0" * 64)
+    assert cli.main(["prepare", "filter", "--metrics", "f.json"]) == 2          # six files done, one reported
+    m = json.load(open("f.json"))
+    assert m["files"] == 6 and m["files_failed"] == 1 and m["failed"][0][0] == bad
+    assert abs(m["audio_seconds"] - sum((3000, 16000, 40000, 2222, 5000, 1000)) / 16000) < 1e-3 and m["audio_s_per_s"] > 0
+    coefs = orc.make_erb_filters(16000, orc.centre_freqs(16000, 128, 100))
+    for b, seed_n in zip(names, ((700, 3000), (701, 16000), (702, 40000))):
+        assert chan_relerr(np.load(b + ".GFB.npy"), orc.erb_filterbank(orc.synth_utterance(*seed_n), coefs)) <= 1e-9
+    os.remove(bad)
+    # resume: nothing to do, then one output removed -> exactly that file again
+    stamp = {b: os.path.getmtime(b + ".GFB.npy") for b in names}
+    assert cli.main(["prepare", "filter", "--skip-existing", "--metrics", "f.json"]) == 0
+    m = json.load(open("f.json"))
+    assert m["files"] == 0 and m["files_skipped"] == 6
+    os.remove(names[2] + ".GFB.npy")
+    assert cli.main(["prepare", "filter", "--skip-existing", "--metrics", "f.json"]) == 0
+    m = json.load(open("f.json"))
+    assert m["files"] == 1 and m["files_skipped"] == 5
+    assert all(os.path.getmtime(b + ".GFB.npy") == stamp[b] for b in names if b != names[2])
+    # envelopes: a truncated .GFB.npy among the inputs
+    raw = open(names[4] + ".GFB.npy", "rb").read()
+    open(names[4] + ".GFB.npy", "wb").write(raw[:len(raw) // 2])
+    assert cli.main(["prepare", "envelope", "-c", "50", "--metrics", "e.json"]) == 2
+    m = json.load(open("e.json"))
+    assert m["files"] == 5 and m["files_failed"] == 1 and m["failed"][0][0].endswith("F4.SA4.GFB.npy")
+    ref = orc.filter_and_envelope(orc.synth_utterance(702, 40000), coefs, True, 50)
+    assert chan_relerr(np.load(names[2] + ".ENV1.npy"), ref) <= 1e-5
+    assert not os.path.exists(names[4] + ".ENV1.npy")
+    # one pass with resume: only the file whose envelope is missing (and its .GFB.npy rewritten)
+    assert cli.main(["prepare", "features", "-c", "50", "--skip-existing", "--metrics", "p.json"]) == 0
+    m = json.load(open("p.json"))
+    assert m["files"] == 1 and m["files_skipped"] == 5 and os.path.exists(names[4] + ".ENV1.npy")
+    capsys.readouterr()

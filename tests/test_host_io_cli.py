@@ -296,3 +296,38 @@ def test_array_pool_recycles_only_unreferenced_owners():
     del t
     gc.collect()
     assert pool.empty(2000).ctypes.data == addr_e
+
+
+def test_job_report_resume_failures_and_metrics(tmp_path, monkeypatch):
+    """The bookkeeping of the file commands (SURVEY section 5 hooks): skip what is up to date, survive unreadable
+    inputs, write the totals as JSON, exit status 2 when something failed."""
+    import json
+    import time
+    from f2cnn_amd.iopipe import JobReport, Unreadable
+    monkeypatch.chdir(tmp_path)
+    srcs = []
+    for i in range(4):
+        p = tmp_path / f"in{i}.WAV"
+        p.write_bytes(b"x")
+        srcs.append(str(p))
+    (tmp_path / "in0.GFB.npy").write_bytes(b"y")                       # fresh output: skipped
+    (tmp_path / "in1.GFB.npy").write_bytes(b"y")
+    os.utime(tmp_path / "in1.GFB.npy", (time.time() - 100, time.time() - 100))   # older than its input: redone
+    outs = lambda name: [os.path.splitext(name)[0] + ".GFB.npy"]
+    rep = JobReport("prepare filter", skip_existing=True, metrics=str(tmp_path / "m.json"))
+    assert rep.pending(srcs, outs) == srcs[1:] and rep.skipped == 1
+    assert JobReport("x").pending(srcs, outs) == srcs                   # without the flag everything runs
+
+    def load(name):
+        if name.endswith("in2.WAV"):
+            raise ValueError("SPHERE sample_coding 'shorten' is not supported")
+        return np.zeros(16000, np.int16)
+    got = [rep.guard(load)(s) for s in srcs[1:]]
+    assert isinstance(got[1], Unreadable) and "shorten" in got[1].reason and not isinstance(got[0], Unreadable)
+    assert rep.add(16000, 16000) == 1 and rep.add(8000, 16000) == 2
+    out = rep.finish()
+    assert rep.exit_status == 2 and out["files"] == 2 and out["files_skipped"] == 1 and out["files_failed"] == 1
+    assert out["audio_seconds"] == 1.5 and out["audio_s_per_s"] > 0
+    assert json.load(open(tmp_path / "m.json"))["failed"][0][0].endswith("in2.WAV")
+    args = cli.build_parser().parse_args(["prepare", "features", "--skip-existing", "--metrics", "m.json", "-c", "50"])
+    assert args.skip_existing and args.metrics == "m.json" and args.CUTOFF == 50
