@@ -9,6 +9,7 @@ import numpy
 
 from ... import _lib
 from ...config import F2Config
+from ...runtime import rank_world
 
 
 def GetListOfEnvelopeFilesAndTimepoints(labelFilename):
@@ -41,7 +42,9 @@ def GenerateInputData(labelFile=None, inputFile=None, LPF=False, CUTOFF=100):
     Row order is part of the file format: envelope files in sorted path order, timepoints of a file in CSV order
     (`cnn train` pairs row i of this matrix with CSV line i, which holds when the CSV itself is path-sorted, as
     `prepare label` writes it). The rows of every file are therefore known before anything is read: each file's block
-    is gathered by K3 straight into its place, while reader threads fetch the next envelope files."""
+    is gathered by K3 straight into its place, while reader threads fetch the next envelope files. With several ranks
+    (F2CNN_RANK / F2CNN_WORLD or torchrun's variables) rank r gathers files r::world into one shared pre-sized .npy
+    (the only cross-rank step of the path, done through the file system, no collective)."""
     started = time.time()
     if not os.path.isdir("trainingData"):
         print("LABEL GENERATION SHOULD BE DONE PRIOR TO INPUT...")
@@ -57,25 +60,82 @@ def GenerateInputData(labelFile=None, inputFile=None, LPF=False, CUTOFF=100):
     first_row = numpy.concatenate([[0], numpy.cumsum([len(per_file[name]) for name in order])])
     print(len(order), "files found along with their", int(first_row[-1]), "entry timepoints.")
     cfg = F2Config()
-    windows = numpy.empty((int(first_row[-1]), cfg.dots_per_input, cfg.nchannels), dtype=numpy.float32)
-    print("Output shape:", windows.shape)
+    shape = (int(first_row[-1]), cfg.dots_per_input, cfg.nchannels)
+    target = inputFile or os.path.join('trainingData',
+                                       'input_data_LPF{}.npy'.format(CUTOFF) if LPF else 'input_data_NOLPF.npy')
+    os.makedirs(os.path.dirname(target) or '.', exist_ok=True)
+    rank, world = rank_world()
+    print("Output shape:", shape)
+    if world == 1:
+        windows = numpy.empty(shape, dtype=numpy.float32)
+    else:
+        # several ranks (one per GPU): every row's place is known up front, so rank 0 creates the pre-sized .npy,
+        # every rank gathers its files r::world straight into it, and rank 0 finishes once all ranks have reported
+        windows = _shared_output(target, shape, rank, world)
 
     def fetch(name):
         return numpy.load(os.path.join('resources', 'f2cnn', name))
+    mine = list(range(len(order)))[rank::world]
     with ThreadPoolExecutor(4) as readers:
-        ahead = [readers.submit(fetch, name) for name in order[:3]]
-        for k, name in enumerate(order):
+        ahead = [readers.submit(fetch, order[k]) for k in mine[:3]]
+        for pos, k in enumerate(mine):
             envelopes = ahead.pop(0).result()
-            if k + 3 < len(order):
-                ahead.append(readers.submit(fetch, order[k + 3]))
-            windows[first_row[k]:first_row[k + 1]] = gather_windows(envelopes, per_file[name], cfg.radius, cfg.step)
-            print("\t\t{:<50} done !  {}/{} Files".format(os.path.join('resources', 'f2cnn', name), k + 1, len(order)))
-    print('Generated Input Matrix of shape {}.'.format(windows.shape))
-    target = inputFile or os.path.join('trainingData',
-                                       'input_data_LPF{}.npy'.format(CUTOFF) if LPF else 'input_data_NOLPF.npy')
+            if pos + 3 < len(mine):
+                ahead.append(readers.submit(fetch, order[mine[pos + 3]]))
+            windows[first_row[k]:first_row[k + 1]] = gather_windows(envelopes, per_file[order[k]], cfg.radius, cfg.step)
+            print("\t\t{:<50} done !  {}/{} Files".format(os.path.join('resources', 'f2cnn', order[k]), k + 1, len(order)))
+    print('Generated Input Matrix of shape {}.'.format(shape))
     print("Saving as {}...".format(target))
-    os.makedirs(os.path.dirname(target) or '.', exist_ok=True)
-    numpy.save(target, windows)
-    numpy.save(os.path.join('trainingData', 'last_input_data.npy'), windows)    # the reference's backup copy (:90)
+    backup = os.path.join('trainingData', 'last_input_data.npy')      # the reference's second copy (:90)
+    if world == 1:
+        numpy.save(target, windows)
+        numpy.save(backup, windows)
+    else:
+        windows.flush()
+        del windows
+        _finish_shared_output(target, backup, rank, world)
     print('                Total time:', time.time() - started)
     print('')
+
+
+def _marker(target, what, rank):
+    return "{}.{}.rank{}".format(target, what, rank)
+
+
+def _shared_output(target, shape, rank, world, timeout=600.0):
+    """The pre-sized output .npy all ranks write into (numpy.lib.format.open_memmap). Rank 0 creates it and announces
+    it; the others wait for the announcement (the ranks of a file command share nothing but the file system)."""
+    if rank == 0:
+        for r in range(world):
+            for what in ("ready", "done"):
+                if os.path.exists(_marker(target, what, r)):
+                    os.remove(_marker(target, what, r))
+        out = numpy.lib.format.open_memmap(target, mode='w+', dtype=numpy.float32, shape=shape)
+        open(_marker(target, "ready", 0), "w").close()
+        return out
+    deadline = time.time() + timeout
+    while not os.path.exists(_marker(target, "ready", 0)):
+        if time.time() > deadline:
+            raise TimeoutError("rank 0 did not create {}".format(target))
+        time.sleep(0.05)
+    out = numpy.lib.format.open_memmap(target, mode='r+')
+    if out.shape != shape or out.dtype != numpy.float32:
+        raise ValueError("{} has shape {} / dtype {}, expected {} float32".format(target, out.shape, out.dtype, shape))
+    return out
+
+
+def _finish_shared_output(target, backup, rank, world, timeout=3600.0):
+    open(_marker(target, "done", rank), "w").close()
+    if rank != 0:
+        return
+    deadline = time.time() + timeout
+    while not all(os.path.exists(_marker(target, "done", r)) for r in range(world)):
+        if time.time() > deadline:
+            raise TimeoutError("not every rank finished its part of {}".format(target))
+        time.sleep(0.05)
+    import shutil
+    if os.path.abspath(backup) != os.path.abspath(target):
+        shutil.copyfile(target, backup)
+    for r in range(world):
+        os.remove(_marker(target, "done", r))
+    os.remove(_marker(target, "ready", 0))

@@ -63,6 +63,23 @@ def test_prepare_and_eval_cli(tmp_path, monkeypatch, capsys):
     for e, (key, tp) in enumerate(order):
         env = np.load(os.path.join("resources", "f2cnn", key + ".ENV1.npy"))
         np.testing.assert_array_equal(x[e], orc.gather_windows(env, [tp])[0].astype(np.float32))
+    # the same with two ranks (two processes on this GPU, F2CNN_RANK / F2CNN_WORLD): each gathers its files r::2 into the
+    # one pre-sized .npy; byte-identical result, backup copy included, no marker files left behind
+    import subprocess
+    import sys
+    single = open("trainingData/input_data_LPF50.npy", "rb").read()
+    os.remove("trainingData/input_data_LPF50.npy")
+    os.remove("trainingData/last_input_data.npy")
+    procs = [subprocess.Popen([sys.executable, "-m", "f2cnn_amd", "prepare", "input", "--cutoff", "50"],
+                              env=dict(os.environ, F2CNN_RANK=str(r), F2CNN_WORLD="2", F2CNN_DEVICE="0",
+                                       PYTHONPATH=os.pathsep.join(sys.path)),
+                              stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for r in (1, 0)]
+    for pr in procs:
+        _, err = pr.communicate(timeout=600)
+        assert pr.returncode == 0, err.decode()[-2000:]
+    assert open("trainingData/input_data_LPF50.npy", "rb").read() == single
+    assert open("trainingData/last_input_data.npy", "rb").read() == single
+    assert sorted(os.listdir("trainingData")) == ["input_data_LPF50.npy", "label_data.csv", "last_input_data.npy"]
     # cnn eval
     F2CNNModel.glorot(7).save("last_trained_model.npz")
     wav = os.path.join("resources", "f2cnn", "TEST", "DR1.FAAA0.SA1.WAV")
