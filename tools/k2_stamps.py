@@ -3,7 +3,8 @@ mean per-workgroup cycle split of k_envelope. Never used for timing."""
 import sys, numpy as np
 sys.path.insert(0, "/root/repo")
 from f2cnn_amd import build
-build.LIB_PATH = "/root/repo/tools/libf2cnn_hip_stamps.so"
+import os
+build.LIB_PATH = os.path.abspath(os.environ.get("F2CNN_PROBE_LIB", "/root/repo/tools/libf2cnn_hip_stamps.so"))
 from f2cnn_amd import _lib
 from f2cnn_amd.gammatone import filters
 import bench
