@@ -451,6 +451,23 @@ constexpr int MAX_LOG2H_F64 = 13;  // rows up to 16384 samples
 
 }  // namespace
 
+#ifdef F2_ENVELOPE_P3_TU
+int f2_launch_envelope13_p3(f2_ctx* ctx, const f2_env_params& P, int precision, unsigned rows) {
+    constexpr int L13 = 13;
+    static_assert(plan_npass(L13) == 3, "this translation unit is compiled with the three-pass plan");
+    if (precision == F2_FFT_F32) {
+        F2_TRY(ensure_twiddles<float>(ctx, L13, ctx->tw_p3[0]));
+        hipLaunchKernelGGL((k_envelope<float, L13>), dim3(rows), dim3(threads_for<float, L13>()), 0, ctx->stream, P,
+                           (const cpx<float>*)ctx->tw_p3[0].ptr);
+    } else {
+        F2_TRY(ensure_twiddles<double>(ctx, L13, ctx->tw_p3[1]));
+        hipLaunchKernelGGL((k_envelope<double, L13>), dim3(rows), dim3(threads_for<double, L13>()), 0, ctx->stream, P,
+                           (const cpx<double>*)ctx->tw_p3[1].ptr);
+    }
+    F2_HIP(ctx, hipGetLastError());
+    return F2_OK;
+}
+#else
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
                        int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, const f2_handoff* handoff) {
     const bool f32_in = handoff && handoff->f32;
@@ -548,7 +565,10 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
                              : (log2h == 13 && precision == F2_FFT_F32) ? F2_THREADS13 : log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
         const dim3 grid((unsigned)(g.size() * (size_t)C)), block(nthreads);
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
-        if (precision == F2_FFT_F32) {
+        if (log2h == 13 && (!P.lpf || precision == F2_FFT_F64) && !getenv("F2CNN_PLAN4")) {
+            // the 1 s row without the float low-pass: three-pass plan (f2_envelope_p3.hip)
+            F2_TRY(f2_launch_envelope13_p3(ctx, P, precision, (unsigned)(g.size() * (size_t)C)));
+        } else if (precision == F2_FFT_F32) {
             F2_TRY(ensure_twiddles<float>(ctx, log2h, ctx->tw[0][log2h]));
             const EnvKernel<float> kern = kernel_for<float, MAX_LOG2H_F32>(log2h);
             hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, P, (const cpx<float>*)ctx->tw[0][log2h].ptr);
@@ -588,3 +608,4 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
 #endif
     return F2_OK;
 }
+#endif  // F2_ENVELOPE_P3_TU

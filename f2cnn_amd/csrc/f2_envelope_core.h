@@ -5,18 +5,7 @@
 
 namespace f2fft {
 
-// kernel arguments shared by the envelope kernels
-struct EnvParams {
-    const double* gfb;
-    double* env;
-    const int64_t* offsets;
-    const int* ulist;  // utterances served by this launch (NULL: identity)
-    int C;
-    int lpf;
-    int f32_in;        // input rows are float32 at the start of their float64 slot (hand-off from K1)
-    unsigned long long* stamps;   // diagnostic build only
-    double b0, a1;     // y[n] = b0 (e[n] + e[n-1]) - a1 y[n-1]
-};
+using EnvParams = ::f2_env_params;   // kernel arguments shared by the envelope kernels (f2_internal.h)
 
 
 template <typename F>

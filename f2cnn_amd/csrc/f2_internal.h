@@ -33,6 +33,7 @@ struct f2_ctx {
     f2_scratch work2;
     f2_scratch xbuf;       // window tensor chunk between K3 and K4
     f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
+    f2_scratch tw_p3[2];   // the same for the three-pass plan of H = 8192 (f2_envelope_p3.hip), [precision]
     f2_scratch tw_large[2][24];   // same for the global-memory transform of long rows
     f2_scratch tw_split[24];      // tables of the four-step transform (f2_envelope_split.hip), by log2 H
     f2_scratch tw_pair[2], pair_list[2];   // two-sub-row transform of 16385..65536-sample rows (f2_envelope_pair.hip): tables, utterance lists
@@ -97,6 +98,24 @@ int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C);
 // failed in between is never closed: it is recycled by the next f2_prof_begin / f2_prof_reset and skipped by f2_prof_get.
 int f2_prof_begin(f2_ctx* ctx, int kernel_id);
 int f2_prof_end(f2_ctx* ctx, int kernel_id);
+
+// kernel arguments shared by the envelope kernels
+struct f2_env_params {
+    const double* gfb;
+    double* env;
+    const int64_t* offsets;
+    const int* ulist;  // utterances served by this launch (NULL: identity)
+    int C;
+    int lpf;
+    int f32_in;        // input rows are float32 at the start of their float64 slot (hand-off from K1)
+    unsigned long long* stamps;   // diagnostic build only
+    double b0, a1;     // y[n] = b0 (e[n] + e[n-1]) - a1 y[n-1]
+};
+// H = 8192 rows (the 1 s / 16 kHz row) with the three-pass plan 16-32-16: f2_envelope_p3.hip compiles f2_envelope.hip
+// a second time with F2_PLAN13_PASSES = 3 - in its own namespace, the radix plans being compile-time functions of the
+// macro - and exports only this launcher. Measured against the four-pass plan: 8 % faster without the low-pass, 6 % with
+// the float64 transform, 4 % slower with the float low-pass; f2_launch_envelope picks per call.
+int f2_launch_envelope13_p3(f2_ctx* ctx, const f2_env_params& P, int precision, unsigned rows);
 
 // longest row (2^22 samples = 262 s at 16 kHz) the global-memory envelope path accepts
 // rows between the LDS limit and 262144 samples: four-step transform with LDS-resident 4096-point parts
