@@ -33,6 +33,7 @@
 // (four-step transform), f2_envelope_large.hip (global-memory passes).
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "f2_fft_lds.h"
 
@@ -93,7 +94,6 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     const double* __restrict__ x = P.gfb + row;
 #endif
     double* __restrict__ y = P.env + row;
-    const bool al16 = (row & 1) == 0;   // row start is 16-byte aligned
 
 #ifdef F2_STAMPS
     unsigned long long st[10] = {0};
@@ -105,83 +105,45 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     constexpr bool FULL0 = NB0 % NT == 0;
     cpx<F> v[PT];
     [[maybe_unused]] F xr[KEEP_X ? ITER0 * R0 : 1], xi[KEEP_X ? ITER0 * R0 : 1];
-    if (KEEP_X && P.f32_in) {
+    // branch-free inside each variant (clamped address + select) so that all loads are in flight together
+    auto load_row = [&](auto* __restrict__ xs, auto odd) {
+#pragma unroll
+        for (int i = 0; i < ITER0; ++i) {
+            const int bf = tid + i * NT;
+            if (FULL0 || bf < NB0) {
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    F a, bb;
+                    row_pair<decltype(odd)::value>(xs, n, 2 * (bf + j * NB0), a, bb);
+                    v[i * R0 + j] = {a, bb};
+                    if constexpr (KEEP_X) {
+                        xr[i * R0 + j] = a;
+                        xi[i * R0 + j] = bb;
+                    }
+                }
+            }
+        }
+    };
+    if (n < 2) {
+        // a one-sample row: M = 1, no pair to load
+        const F a = (KEEP_X && P.f32_in) ? (F) reinterpret_cast<const float*>(x)[0] : (F)x[0];
+#pragma unroll
+        for (int q = 0; q < ITER0 * R0; ++q) {
+            v[q] = {F(0), F(0)};
+            if constexpr (KEEP_X) xr[q] = xi[q] = F(0);
+        }
+        if (tid == 0) {
+            v[0] = {a, F(0)};
+            if constexpr (KEEP_X) xr[0] = a;
+        }
+    } else if (KEEP_X && P.f32_in) {
         // float32 hand-off from the filterbank kernel: the row's samples sit at the start of its float64 slot
         const float* __restrict__ xf = reinterpret_cast<const float*>(x);
-        // branch-free (clamped address + select) so that all loads are in flight together
-        const int last = n - 1;
-        if ((n & 1) == 0) {
-#pragma unroll
-            for (int i = 0; i < ITER0; ++i) {
-                const int bf = tid + i * NT;
-                if (FULL0 || bf < NB0) {
-#pragma unroll
-                    for (int j = 0; j < R0; ++j) {
-                        const int i0 = 2 * (bf + j * NB0);
-                        const f2_f2 t = load_pair_f32(xf + min(i0, n - 2));
-                        v[i * R0 + j] = {i0 < n ? (F)t.x : F(0), i0 < n ? (F)t.y : F(0)};
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < ITER0; ++i) {
-                const int bf = tid + i * NT;
-                if (FULL0 || bf < NB0) {
-#pragma unroll
-                    for (int j = 0; j < R0; ++j) {
-                        const int i0 = 2 * (bf + j * NB0);
-                        const float t0 = xf[min(i0, last)], t1 = xf[min(i0 + 1, last)];
-                        v[i * R0 + j] = {i0 < n ? (F)t0 : F(0), i0 + 1 < n ? (F)t1 : F(0)};
-                    }
-                }
-            }
-        }
-        if constexpr (KEEP_X) {
-#pragma unroll
-            for (int q = 0; q < ITER0 * R0; ++q) {
-                xr[q] = v[q].re;
-                xi[q] = v[q].im;
-            }
-        }
-    } else if (al16 && (n & 1) == 0 && n >= 2) {
-        // common case: 16-byte loads, no branches (clamped address + select for the zero padding)
-#pragma unroll
-        for (int i = 0; i < ITER0; ++i) {
-            const int bf = tid + i * NT;
-            if (FULL0 || bf < NB0) {
-#pragma unroll
-                for (int j = 0; j < R0; ++j) {
-                    const int i0 = 2 * (bf + j * NB0);
-                    const f2_d2 t = load_pair_f64(x + min(i0, n - 2));
-                    const F a = i0 < n ? (F)t.x : F(0), bb = i0 < n ? (F)t.y : F(0);
-                    v[i * R0 + j] = {a, bb};
-                    if constexpr (KEEP_X) {
-                        xr[i * R0 + j] = a;
-                        xi[i * R0 + j] = bb;
-                    }
-                }
-            }
-        }
+        if ((n & 1) == 0) load_row(xf, std::false_type{});
+        else load_row(xf, std::true_type{});
     } else {
-#pragma unroll
-        for (int i = 0; i < ITER0; ++i) {
-            const int bf = tid + i * NT;
-            if (FULL0 || bf < NB0) {
-#pragma unroll
-                for (int j = 0; j < R0; ++j) {
-                    const int i0 = 2 * (bf + j * NB0);
-                    const double t0 = x[min(i0, n - 1)], t1 = x[min(i0 + 1, n - 1)];   // clamped: no branches
-                    const F a = i0 < n ? (F)t0 : F(0);
-                    const F bb = i0 + 1 < n ? (F)t1 : F(0);
-                    v[i * R0 + j] = {a, bb};
-                    if constexpr (KEEP_X) {
-                        xr[i * R0 + j] = a;
-                        xi[i * R0 + j] = bb;
-                    }
-                }
-            }
-        }
+        if ((n & 1) == 0) load_row(x, std::false_type{});
+        else load_row(x, std::true_type{});
     }
     F2_STAMP(1);
     // 2. forward transform (first pass straight from the registers)
@@ -251,31 +213,14 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
         }
     }
     if (!P.lpf) {
-        if (al16 && (n & 1) == 0) {
 #pragma unroll
-            for (int i = 0; i < ITER0; ++i) {
-                const int bf = tid + i * NT;
-                if (FULL0 || bf < NB0) {
+        for (int i = 0; i < ITER0; ++i) {
+            const int bf = tid + i * NT;
+            if (FULL0 || bf < NB0) {
 #pragma unroll
-                    for (int j = 0; j < R0; ++j) {
-                        const int i0 = 2 * (bf + j * NB0);
-                        const cpx<F> e = v[i * R0 + brev<R0>(j)];
-                        if (i0 < n) store_pair(y + i0, (double)e.re, (double)e.im);
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < ITER0; ++i) {
-                const int bf = tid + i * NT;
-                if (FULL0 || bf < NB0) {
-#pragma unroll
-                    for (int j = 0; j < R0; ++j) {
-                        const int i0 = 2 * (bf + j * NB0);
-                        const cpx<F> e = v[i * R0 + brev<R0>(j)];
-                        if (i0 < n) y[i0] = (double)e.re;
-                        if (i0 + 1 < n) y[i0 + 1] = (double)e.im;
-                    }
+                for (int j = 0; j < R0; ++j) {
+                    const cpx<F> e = v[i * R0 + brev<R0>(j)];
+                    store_row_pair(y, n, 2 * (bf + j * NB0), (double)e.re, (double)e.im);
                 }
             }
         }
@@ -294,7 +239,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
                 er[i + ITER0 * j] = v[i * R0 + brev<R0>(j)].re;
                 ei[i + ITER0 * j] = v[i * R0 + brev<R0>(j)].im;
             }
-        lowpass_pairs_store<F, NT, NBLK>(er, ei, P.a1, P.b0, smem, y, n, al16 && (n & 1) == 0, tid);
+        lowpass_pairs_store<F, NT, NBLK>(er, ei, P.a1, P.b0, smem, y, n, tid);
 #ifdef F2_STAMPS
         F2_STAMP(6);
         st[7] = st[8] = st[9] = st[6];
@@ -413,18 +358,8 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     }
     __syncthreads();
     F2_STAMP(8);
-    if (al16) {
 #pragma unroll 4
-        for (int i = 2 * tid; i < n; i += 2 * NT) {
-            if (i + 1 < n)
-                *reinterpret_cast<double2*>(y + i) = make_double2((double)rl[tpos(i)], (double)rl[tpos(i + 1)]);
-            else
-                y[i] = (double)rl[tpos(i)];
-        }
-    } else {
-#pragma unroll 4
-        for (int i = tid; i < n; i += NT) y[i] = (double)rl[tpos(i)];
-    }
+    for (int i = 2 * tid; i < n; i += 2 * NT) store_row_pair(y, n, i, (double)rl[tpos(i)], (double)rl[tpos(min(i + 1, n - 1))]);
 #ifdef F2_STAMPS
     F2_STAMP(9);
     if (tid == 0 && P.stamps)

@@ -90,27 +90,55 @@ constexpr int brev(int k) {
 // with non-temporal loads of the hand-off; -DF2_TEMPORAL restores plain accesses).
 typedef double f2_d2 __attribute__((ext_vector_type(2)));
 typedef float f2_f2 __attribute__((ext_vector_type(2)));
+// A row of a (C, n) matrix starts on an element boundary, not on a pair boundary (odd n: every other row). Global
+// memory takes dword-aligned wide accesses, so pairs are always moved as one 16-byte (float64) or 8-byte (float32)
+// access through these under-aligned types, whatever the parity of the row.
+typedef f2_d2 f2_d2u __attribute__((aligned(8)));
+typedef f2_f2 f2_f2u __attribute__((aligned(4)));
 __device__ __forceinline__ void store_pair(double* p, double a, double b) {
-    f2_d2 v = {a, b};
+    f2_d2u v = {a, b};
 #ifdef F2_TEMPORAL
-    *reinterpret_cast<f2_d2*>(p) = v;
+    *reinterpret_cast<f2_d2u*>(p) = v;
 #else
-    __builtin_nontemporal_store(v, reinterpret_cast<f2_d2*>(p));
+    __builtin_nontemporal_store(v, reinterpret_cast<f2_d2u*>(p));
 #endif
 }
 __device__ __forceinline__ f2_d2 load_pair_f64(const double* p) {
 #ifdef F2_TEMPORAL
-    return *reinterpret_cast<const f2_d2*>(p);
+    return *reinterpret_cast<const f2_d2u*>(p);
 #else
-    return __builtin_nontemporal_load(reinterpret_cast<const f2_d2*>(p));
+    return __builtin_nontemporal_load(reinterpret_cast<const f2_d2u*>(p));
 #endif
 }
 __device__ __forceinline__ f2_f2 load_pair_f32(const float* p) {
 #ifdef F2_TEMPORAL
-    return *reinterpret_cast<const f2_f2*>(p);
+    return *reinterpret_cast<const f2_f2u*>(p);
 #else
-    return __builtin_nontemporal_load(reinterpret_cast<const f2_f2*>(p));
+    return __builtin_nontemporal_load(reinterpret_cast<const f2_f2u*>(p));
 #endif
+}
+// Samples i0 and i0 + 1 (i0 even, any value >= 0) of a row of n >= 2 samples, zero beyond its end: one wide load from
+// an address clamped into the row, no divergent loads. ODD = false is the cheaper form for rows of even length (a
+// pair is inside the row or outside it); with ODD the last sample of an odd-length row arrives as the second half of
+// the pair (n-2, n-1). Callers branch on the parity of n once, outside their unrolled loops.
+template <bool ODD, typename F>
+__device__ __forceinline__ void row_pair(const float* __restrict__ x, int n, int i0, F& a, F& b) {
+    const int p = min(i0, n - 2);
+    const f2_f2 t = load_pair_f32(x + p);
+    a = i0 < n ? (F)((!ODD || p == i0) ? t.x : t.y) : F(0);
+    b = (ODD ? i0 + 1 < n : i0 < n) ? (F)t.y : F(0);
+}
+template <bool ODD, typename F>
+__device__ __forceinline__ void row_pair(const double* __restrict__ x, int n, int i0, F& a, F& b) {
+    const int p = min(i0, n - 2);
+    const f2_d2 t = load_pair_f64(x + p);
+    a = i0 < n ? (F)((!ODD || p == i0) ? t.x : t.y) : F(0);
+    b = (ODD ? i0 + 1 < n : i0 < n) ? (F)t.y : F(0);
+}
+// envelope samples i0, i0 + 1 of a row of n samples
+__device__ __forceinline__ void store_row_pair(double* __restrict__ y, int n, int i0, double a, double b) {
+    if (i0 + 1 < n) store_pair(y + i0, a, b);
+    else if (i0 < n) y[i0] = a;
 }
 
 __device__ __forceinline__ double shfl_up_f64(double v, int d) {
@@ -153,8 +181,8 @@ constexpr size_t lowpass_lds_bytes() {
 // 2*NT*NBLK samples (rows longer than that are filtered segment by segment, f2_envelope_split.hip).
 template <typename F, int NT, int NBLK>
 __device__ __forceinline__ double lowpass_pairs_store(const F (&er)[NBLK], const F (&ei)[NBLK], double a1, double b0,
-                                                      unsigned char* smem, double* __restrict__ y, int n, bool pairs_ok,
-                                                      int tid, double y_in = 0.0, F e_in = F(0)) {
+                                                      unsigned char* smem, double* __restrict__ y, int n, int tid,
+                                                      double y_in = 0.0, F e_in = F(0)) {
     constexpr int NW = NT / 64;
     static_assert(NBLK <= NT, "one thread per block chains the wave totals");
     F* e1s = reinterpret_cast<F*>(smem);                           // [NBLK][NT] odd samples, for e[n-1]
@@ -260,12 +288,7 @@ __device__ __forceinline__ double lowpass_pairs_store(const F (&er)[NBLK], const
         const F y0 = qf * (gtf * (F)ycarry + sprev) + u0[jj];
         const F y1 = qf * y0 + u1[jj];
         const int i0 = 2 * (tid + NT * jj);
-        if (pairs_ok) {
-            if (i0 < n) store_pair(y + i0, (double)y0, (double)y1);
-        } else {
-            if (i0 < n) y[i0] = (double)y0;
-            if (i0 + 1 < n) y[i0 + 1] = (double)y1;
-        }
+        store_row_pair(y, n, i0, (double)y0, (double)y1);
         ycarry = fma(gblk, ycarry, btot[jj]);
     }
     return ycarry;

@@ -57,18 +57,12 @@ struct PairParams {
     const cpx<float>* vo;      // [HS/2] (cos, -sin)(pi (2j+1) / H): pair-step angles of the odd sub-row
 };
 
-// samples i0, i0 + 1 (i0 even) of a row of n samples as floats, 0 beyond the end; clamped addresses, no divergent
-// loads. EVEN: n is even and the row is aligned for one load per pair.
-template <typename T, bool EVEN>
+// samples i0, i0 + 1 (i0 even) of a row of n samples as floats, 0 beyond the end
+template <typename T>
 __device__ __forceinline__ cpx<float> load_pair(const T* __restrict__ x, int n, int i0) {
-    if constexpr (EVEN) {
-        typedef T T2 __attribute__((ext_vector_type(2)));
-        const T2 t = *reinterpret_cast<const T2*>(x + min(i0, n - 2));
-        return {i0 < n ? (float)t.x : 0.f, i0 < n ? (float)t.y : 0.f};
-    } else {
-        const T va = x[min(i0, n - 1)], vb = x[min(i0 + 1, n - 1)];
-        return {i0 < n ? (float)va : 0.f, i0 + 1 < n ? (float)vb : 0.f};
-    }
+    cpx<float> r;
+    row_pair<true>(x, n, i0, r.re, r.im);
+    return r;
 }
 
 // forward transform of the sub-row in v, Hilbert pair step in LDS, second transform back into v
@@ -126,9 +120,8 @@ __device__ __forceinline__ void sub_row(cpx<float>* lds, const cpx<float>* __res
     fft_all<float, LOG2S, true, PT, NT, T0R>(lds, tw, twl, tid, v);        // point tid + j*NB0 in v[brev<R0>(j)]
 }
 
-// T: float (the filterbank's compact float32 hand-off rows) or double (a float64 filterbank matrix); EVEN: every row of
-// the launch has an even length and starts on a 2-element boundary, so a pair is one load (the host groups the utterances).
-template <int LOG2S, typename T, bool EVEN>
+// T: float (the filterbank's compact float32 hand-off rows) or double (a float64 filterbank matrix)
+template <int LOG2S, typename T>
 __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParams P, const cpx<float>* __restrict__ tw) {
     constexpr int HS = Geo<LOG2S>::HS, NT = Geo<LOG2S>::NT, PT = Geo<LOG2S>::PT, R0 = Geo<LOG2S>::R0, NB0 = Geo<LOG2S>::NB0;
     constexpr int CS = cpad_size(HS);
@@ -165,7 +158,7 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
 #pragma unroll
         for (int j = j0; j < j0 + LOADCHUNK; ++j) {
             const int m = tid + j * NB0;
-            const cpx<float> z0 = load_pair<T, EVEN>(x, n, 2 * m), z1 = load_pair<T, EVEN>(x, n, 2 * (m + HS));
+            const cpx<float> z0 = load_pair<T>(x, n, 2 * m), z1 = load_pair<T>(x, n, 2 * (m + HS));
             v[j] = z0 + z1;
             park_b[m] = cmul(z0 - z1, P.tx[m]);
         }
@@ -182,7 +175,6 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
     // envelopes stay in registers until every thread has read its parked points (they overwrite the parking area);
     // the upper half's positions lie beyond it and are written at once - final float64 values without low-pass, else
     // the float pair at the start of its own 16-byte output position, where it waits for the second low-pass segment.
-    const bool pairs_ok = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     float er[R0], ei[R0];
 #pragma unroll
     for (int j0 = 0; j0 < R0; j0 += 4) {
@@ -192,7 +184,7 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
             asm volatile("" : "+v"(m));       // (keeps the compiler from holding the load stage's 32 addresses until here)
             const cpx<float> e = park_e[m];
             const cpx<float> o = cmul(v[brev<R0>(j)], P.tx[m]);
-            const cpx<float> x0 = load_pair<T, EVEN>(x, n, 2 * m), x1 = load_pair<T, EVEN>(x, n, 2 * (m + HS));
+            const cpx<float> x0 = load_pair<T>(x, n, 2 * m), x1 = load_pair<T>(x, n, 2 * (m + HS));
             const float lr = 0.5f * (e.re + o.re), li = 0.5f * (e.im + o.im);
             const float ur = 0.5f * (e.re - o.re), ui = 0.5f * (e.im - o.im);
             er[j] = fsqrt(x0.re * x0.re + lr * lr);
@@ -201,11 +193,8 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
             const int i1 = 2 * (m + HS);
             if (P.lpf) {
                 if (i1 < n) *reinterpret_cast<cpx<float>*>(y + i1) = {hr, hi};
-            } else if (pairs_ok && i1 + 1 < n) {
-                *reinterpret_cast<double2*>(y + i1) = make_double2((double)hr, (double)hi);
             } else {
-                if (i1 < n) y[i1] = (double)hr;
-                if (i1 + 1 < n) y[i1 + 1] = (double)hi;
+                store_row_pair(y, n, i1, (double)hr, (double)hi);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -215,17 +204,11 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
     if (!P.lpf) {
 #pragma unroll
         for (int j = 0; j < R0; ++j) {
-            const int i0 = 2 * (tid + j * NB0);              // i0 + 1 < 2 HS < n
-            if (pairs_ok) {
-                *reinterpret_cast<double2*>(y + i0) = make_double2((double)er[j], (double)ei[j]);
-            } else {
-                y[i0] = (double)er[j];
-                y[i0 + 1] = (double)ei[j];
-            }
+            store_pair(y + 2 * (tid + j * NB0), (double)er[j], (double)ei[j]);   // i0 + 1 < 2 HS < n
         }
         return;
     }
-    const double ycarry = lowpass_pairs_store<float, NT, R0>(er, ei, P.a1, P.b0, smem, y, 2 * HS, pairs_ok, tid);
+    const double ycarry = lowpass_pairs_store<float, NT, R0>(er, ei, P.a1, P.b0, smem, y, 2 * HS, tid);
 #pragma unroll
     for (int j = 0; j < R0; ++j) {
         const int i1 = 2 * (tid + j * NB0 + HS);
@@ -234,8 +217,7 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
         ei[j] = i1 + 1 < n ? p.im : 0.f;
     }
     __syncthreads();   // the scan's last LDS reads precede the next segment's writes
-    lowpass_pairs_store<float, NT, R0>(er, ei, P.a1, P.b0, smem, y + 2 * HS, n - 2 * HS, pairs_ok && ((n & 1) == 0), tid,
-                                       ycarry, *e_mid_p);
+    lowpass_pairs_store<float, NT, R0>(er, ei, P.a1, P.b0, smem, y + 2 * HS, n - 2 * HS, tid, ycarry, *e_mid_p);
 }
 
 template <int LOG2S>
@@ -266,23 +248,10 @@ int launch_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* 
     f2_scratch& tables = ctx->tw_pair[LOG2S - 13];
     F2_TRY(ensure_pair_tables<LOG2S>(ctx, tables));
     F2_TRY(ensure_twiddles<float>(ctx, LOG2S, ctx->tw[0][LOG2S]));
-    // utterances whose rows all have an even length and start on an even element first: their pairs are single loads
-    auto is_even = [&](int b) {
-        const int64_t n = h_offsets[b + 1] - h_offsets[b];
-        const int64_t base = d_x32 ? h_x32_off[b] : (int64_t)C * h_offsets[b];
-        return (n % 2 == 0) && (base % 2 == 0);
-    };
-    std::vector<int> order;
-    order.reserve((size_t)nutt);
-    for (int i = 0; i < nutt; ++i)
-        if (is_even(utts[i])) order.push_back(utts[i]);
-    const int n_even = (int)order.size();
-    for (int i = 0; i < nutt; ++i)
-        if (!is_even(utts[i])) order.push_back(utts[i]);
     f2_scratch& list = ctx->pair_list[LOG2S - 13];
     F2_TRY(f2_reserve(ctx, list, sizeof(int) * (size_t)nutt));
-    F2_HIP(ctx, hipMemcpyAsync(list.ptr, order.data(), sizeof(int) * (size_t)nutt, hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `order` is a local
+    F2_HIP(ctx, hipMemcpyAsync(list.ptr, utts, sizeof(int) * (size_t)nutt, hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `utts` belongs to the caller
     PairParams P;
     P.gfb = d_gfb;
     P.env = d_env;
@@ -296,24 +265,16 @@ int launch_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* 
     P.x32_off = d_x32_off;
     P.tx = (const cpx<float>*)tables.ptr;
     P.vo = P.tx + HS;
-    for (int even = 0; even < 2; ++even) {
-        const int cnt = even ? n_even : nutt - n_even;
-        if (cnt == 0) continue;
-        P.ulist = (const int*)list.ptr + (even ? 0 : n_even);
-        const dim3 grid((unsigned)((size_t)cnt * C)), block(NT);
-        const cpx<float>* tw = (const cpx<float>*)ctx->tw[0][LOG2S].ptr;
-        F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
-        if (d_x32 && even)
-            hipLaunchKernelGGL((k_envelope_pair<LOG2S, float, true>), grid, block, 0, ctx->stream, P, tw);
-        else if (d_x32)
-            hipLaunchKernelGGL((k_envelope_pair<LOG2S, float, false>), grid, block, 0, ctx->stream, P, tw);
-        else if (even)
-            hipLaunchKernelGGL((k_envelope_pair<LOG2S, double, true>), grid, block, 0, ctx->stream, P, tw);
-        else
-            hipLaunchKernelGGL((k_envelope_pair<LOG2S, double, false>), grid, block, 0, ctx->stream, P, tw);
-        F2_HIP(ctx, hipGetLastError());
-        F2_TRY(f2_prof_end(ctx, F2_K_ENVELOPE));
-    }
+    P.ulist = (const int*)list.ptr;
+    const dim3 grid((unsigned)((size_t)nutt * C)), block(NT);
+    const cpx<float>* tw = (const cpx<float>*)ctx->tw[0][LOG2S].ptr;
+    F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
+    if (d_x32)
+        hipLaunchKernelGGL((k_envelope_pair<LOG2S, float>), grid, block, 0, ctx->stream, P, tw);
+    else
+        hipLaunchKernelGGL((k_envelope_pair<LOG2S, double>), grid, block, 0, ctx->stream, P, tw);
+    F2_HIP(ctx, hipGetLastError());
+    F2_TRY(f2_prof_end(ctx, F2_K_ENVELOPE));
     return F2_OK;
 }
 

@@ -69,12 +69,12 @@ __device__ __forceinline__ Row row_of(const SplitParams& P, int r) {
     const float* xf = P.x32 ? P.x32 + P.x32_off[b] + (size_t)c * (size_t)n : nullptr;
     return {P.gfb + row, xf, P.env + row, n};
 }
-// samples i0, i0 + 1 of the row as floats (0 beyond the end); clamped addresses, no divergent loads
+// samples i0, i0 + 1 of the row as floats (0 beyond the end): one wide load from a clamped address
 __device__ __forceinline__ cpx<float> load_pair(const Row& rw, int i0) {
-    const int a = min(i0, rw.n - 1), b = min(i0 + 1, rw.n - 1);
-    const float va = rw.xf ? rw.xf[a] : (float)rw.x[a];
-    const float vb = rw.xf ? rw.xf[b] : (float)rw.x[b];
-    return {i0 < rw.n ? va : 0.f, i0 + 1 < rw.n ? vb : 0.f};
+    cpx<float> r;
+    if (rw.xf) row_pair<true>(rw.xf, rw.n, i0, r.re, r.im);
+    else row_pair<true>(rw.x, rw.n, i0, r.re, r.im);
+    return r;
 }
 
 template <int H1>
@@ -166,7 +166,6 @@ __global__ __launch_bounds__(256) void k_split_last(SplitParams P) {
         v[k1] = k1 == 0 ? c : cmul(c, P.twa[k1 * H2 + m2]);
     }
     dft<H1>(v);   // w~[m2 + H2 m1] in v[brev<H1>(m1)]
-    const bool pairs_ok = (reinterpret_cast<uintptr_t>(rw.y) & 15) == 0;
 #pragma unroll
     for (int m1 = 0; m1 < H1; ++m1) {
         const int i0 = 2 * (m2 + H2 * m1);
@@ -179,13 +178,7 @@ __global__ __launch_bounds__(256) void k_split_last(SplitParams P) {
             Ce[m1 * H2 + m2] = {f0, f1};
             continue;
         }
-        const double e0 = (double)f0, e1 = (double)f1;
-        if (i0 + 1 < rw.n && pairs_ok) {
-            *reinterpret_cast<double2*>(rw.y + i0) = make_double2(e0, e1);
-        } else {
-            if (i0 < rw.n) rw.y[i0] = e0;
-            if (i0 + 1 < rw.n) rw.y[i0 + 1] = e1;
-        }
+        store_row_pair(rw.y, rw.n, i0, (double)f0, (double)f1);
     }
 }
 
@@ -200,7 +193,6 @@ __global__ __launch_bounds__(LNT, 4) void k_split_lowpass(SplitParams P) {
     const Row rw = row_of(P, blockIdx.x);
     double* y = rw.y;
     const int n = rw.n;
-    const bool al16 = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     const cpx<float>* __restrict__ e = P.scratch + (size_t)blockIdx.x * (H1 * H2);   // envelope pairs left by k_split_last
     double ycarry = 0.0;
     float ecarry = 0.f;
@@ -217,8 +209,7 @@ __global__ __launch_bounds__(LNT, 4) void k_split_lowpass(SplitParams P) {
         if (tid == LNT - 1) e_last = ei[LNB - 1];   // e[-1] of the next segment
         __syncthreads();   // every load of this segment precedes every store; smem and e_last are settled
         const float e_next = e_last;
-        ycarry = lowpass_pairs_store<float, LNT, LNB>(er, ei, P.a1, P.b0, smem, y + base, left, al16 && (left & 1) == 0,
-                                                      tid, ycarry, ecarry);
+        ycarry = lowpass_pairs_store<float, LNT, LNB>(er, ei, P.a1, P.b0, smem, y + base, left, tid, ycarry, ecarry);
         __syncthreads();   // the scan's last LDS reads precede the next segment's writes (smem, e_last)
         ecarry = e_next;
     }

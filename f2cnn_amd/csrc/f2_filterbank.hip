@@ -8,9 +8,21 @@
 // block of TB samples is staged once in LDS (fetched one block ahead) and read back as a broadcast.
 //
 // The (C,N) C-order output would make every lane store to its own row (stride N*8 bytes). Instead a
-// TB-sample block of results is written to an LDS tile [64 lanes][TB+1] (pad 1 double: conflict-free
-// ds_write_b64 column writes) and then streamed out row by row, so every global store instruction
-// covers 64/TB full row segments of TB*8 contiguous bytes.
+// TB-sample block of results is written to an LDS tile (one row per lane) and then streamed out row by row, so every
+// global store instruction covers 64/TB row segments of 128 contiguous bytes.
+//
+// Those segments must also START on a 128-byte line, or every store leaves two partly written lines behind that
+// the next tile of the same row completes microseconds later - by then evicted from L2 (8 GB stream through it),
+// and a partial write costs HBM a read-modify-write: measured 2.3x on the whole kernel for rows that are not
+// aligned (n = 15999 or 16002 against 16000; 64-byte alignment still costs 15-50 %) - and real utterance lengths
+// are arbitrary. So each row is stored with its own lag d = (element index of its first sample) mod TB: after
+// tile [t0, t0+TB) the samples [t0 - d, t0 - d + TB) of the row go out, one aligned 128-byte line. In LDS a row
+// has 2 TB columns; a lane writes its tile to columns [d, d + TB), keeps it in registers as well and, after the
+// store phase, copies it to columns (d + j + TB) mod 2 TB - which puts the last d samples at [0, d), in front of
+// the next tile (the others land in the unused columns behind it) - through addresses computed once per
+// utterance. The store phase therefore reads the fixed columns [0, TB) of every row, and the rows of one store
+// instruction (q, q + RQ, ...) share their lag: every address of the store phase is wave-uniform base + fixed lane
+// offset.
 //
 // Bound: the float64 FMA pipe (13 ops per sample-channel; 17 in the general form); HBM traffic is 8*C*N bytes
 // written per utterance (4*C*N as the float32 hand-off to K2) + 2*N read.
@@ -21,14 +33,21 @@
 
 namespace {
 
-constexpr int TB = 32;                 // samples per LDS tile
-constexpr int ROWS_PER_STORE = 64 / TB;
+template <typename OutT>
+struct TileGeo {
+    static constexpr int TB = 128 / (int)sizeof(OutT);       // samples per tile = one 128-byte line of a row (lag < TB)
+    static constexpr int RPS = 64 / TB;                      // rows per store instruction
+    static constexpr int RQ = 64 / RPS;                      // store instructions per tile; RQ * pitch % TB == 0
+    static constexpr int W = 2 * TB;                         // columns of a row in LDS
+    static constexpr int PITCH = W + 1;                      // (odd in words / 2 mod 4: conflict-free column writes)
+};
+constexpr int SEG_ALIGN = 32;   // host: segment lengths of the time-split path, a multiple of every tile size
 // Wavefronts per workgroup. The waves of a workgroup are independent (own utterance/channel group, own LDS tile, no
 // workgroup barrier); they only share a workgroup so that the dispatcher places them one per SIMD of a CU. With
 // one-wave workgroups the 2000 waves of the benchmark batch land unevenly (some SIMDs run three, others one) and the
 // kernel takes as long as the fullest SIMD.
 #ifndef F2_K1_WAVES_F32
-#define F2_K1_WAVES_F32 4     // float32 hand-off tiles: 4 x 8.4 KB of LDS
+#define F2_K1_WAVES_F32 4     // float32 hand-off tiles: 4 x 16.6 KB of LDS
 #endif
 #ifndef F2_K1_WAVES_F64
 #define F2_K1_WAVES_F64 2     // float64 output tiles: 2 x 16.9 KB (the store-bound variant gains nothing beyond two)
@@ -61,7 +80,7 @@ __device__ __forceinline__ void wave_sync() {
 // Twice the arithmetic, 1/K of the latency (+ the chain); the results differ from the serial run by float64 rounding.
 struct SplitArgs {
     int K;                  // segments per utterance
-    int L;                  // samples per segment (multiple of TB)
+    int L;                  // samples per segment (multiple of SEG_ALIGN)
     double* states;         // [unit][K][8][64 lanes]: E of every segment
     const double* mtab;     // [C][8][8]: M = T^L, row major
     const int* order;       // MODE 3: units in the order they are handed out (longest first)
@@ -74,8 +93,10 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
                                                 const double* __restrict__ coefs, int C, int groups,
                                                 double* __restrict__ out, float* __restrict__ alt,
                                                 const int64_t* __restrict__ alt_off, const SplitArgs& sp, int unit, int seg,
-                                                int lane, int wid, OutT (*tile)[TB + 1], double* xs,
+                                                int lane, OutT (*tile)[TileGeo<OutT>::PITCH], double* xs,
                                                 double (*mshw)[64]) {
+    using G = TileGeo<OutT>;
+    constexpr int TB = G::TB, RQ = G::RQ, PITCH = G::PITCH;
     const int K = (MODE == 1 || MODE == 2) ? sp.K : 1;
     const int b = unit / groups;
     const int c0 = (unit % groups) * 64;
@@ -141,7 +162,46 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
     // byte offsets inside this utterance's block fit 32 bits up to 512 Mi sample-channels
     const bool fits32 = (uint64_t)C * (uint64_t)N * 8u < (uint64_t(1) << 32);
     const bool full_rows = c0 + 64 <= C;
-    const uint32_t rstep = (uint32_t)(ROWS_PER_STORE * N * ROWMUL * sizeof(OutT));
+    // row pitch in elements, 128-byte phase of row c0, and this lane's own row: its tile goes to columns [d_lane, d_lane + TB)
+    const int64_t pitch = N * ROWMUL;
+    const int pstep = (int)(pitch & (TB - 1));
+    const int phase_c0 = (int)((reinterpret_cast<uintptr_t>(obase) / sizeof(OutT) + (uint64_t)c0 * (uint64_t)pitch) & (TB - 1));
+    const int d_lane = (phase_c0 + lane * pstep) & (TB - 1);
+    const bool lagged = (pstep | phase_c0) != 0;              // wave-uniform; false: every row starts on a line, d = 0
+    OutT* const wb = &tile[lane][d_lane];
+    const OutT* const rb = &tile[srow * RQ][scol];            // row q + srow*RQ of store q: rb + q*PITCH
+    [[maybe_unused]] OutT* carry[TB];                         // where sample j of a tile waits for the next window
+    if constexpr (MODE != 1) {
+#pragma unroll
+        for (int j = 0; j < TB; ++j) carry[j] = &tile[lane][(d_lane + j + TB) & (2 * TB - 1)];
+    }
+    OutT* const orow = reinterpret_cast<OutT*>(obase) + (size_t)c0 * (size_t)pitch;
+    const uint32_t voff = (uint32_t)(((size_t)(srow * RQ) * (size_t)pitch + (size_t)scol) * sizeof(OutT));   // (fits32)
+    // Samples [t0 - d, t0 - d + TB) of every row, d the row's lag; `fast`: all of them inside [t_begin, t_end), all 64
+    // rows exist, offsets fit 32 bits - wave-uniform row base + fixed lane offset, no checks.
+    auto store_window = [&](int64_t t0, bool fast) {
+        int dq = phase_c0;
+        if (fast) {
+            OutT vals[RQ];   // all LDS reads first (distinct registers), then the stores: no load-use wait per row
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) vals[q] = rb[q * PITCH];
+            const char* base = reinterpret_cast<const char*>(orow + t0);
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                char* p = const_cast<char*>(base) + ((int64_t)q * pitch - dq) * (int64_t)sizeof(OutT);
+                *reinterpret_cast<OutT*>(p + voff) = vals[q];
+                dq = (dq + pstep) & (TB - 1);
+            }
+        } else {
+#pragma unroll 8
+            for (int q = 0; q < RQ; ++q) {
+                const int row = q + srow * RQ;
+                const int64_t t = t0 - dq + scol;
+                if (t >= t_begin && t < t_end && c0 + row < C) orow[(size_t)row * (size_t)pitch + (size_t)t] = rb[q * PITCH];
+                dq = (dq + pstep) & (TB - 1);
+            }
+        }
+    };
 
     // The input block is fetched one block ahead: vmcnt retires in issue order (stores included), so a load
     // issued after a block's 32 row stores would make the wave wait for those stores every block.
@@ -157,6 +217,7 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
         // out skewed -- step s runs section k on sample s-k+1 -- so that every step holds four independent
         // recurrences and the in-order VALU always has a ready float64 FMA.
         double p1 = 0, p2 = 0, p3 = 0;
+        [[maybe_unused]] OutT tail[TB];   // this lane's row of the tile
         if constexpr (A2ZERO) {
             // Numerators T + A1k z^-1 = T (1 + ck z^-1): each section in direct form II costs three FMAs,
             //   w = in - a1 w[-1] - a2 w[-2] ;  out = w + ck w[-1]
@@ -185,7 +246,11 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
                 }
                 if (s2 >= 3) {
                     const double wv = fma(-a1, z40, fma(-a2, z41, p3));
-                    if constexpr (MODE != 1) tile[lane][s2 - 3] = (OutT)(fma(c4, z40, wv) * scale);
+                    if constexpr (MODE != 1) {
+                        const OutT y = (OutT)(fma(c4, z40, wv) * scale);
+                        wb[s2 - 3] = y;
+                        tail[s2 - 3] = y;
+                    }
                     z41 = z40;
                     z40 = wv;
                 }
@@ -221,7 +286,8 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
                     const double y4 = fma(b0g, p3, z40);
                     z40 = fma(-a1, y4, fma(b14g, p3, z41));
                     z41 = fma(b2g, p3, -a2 * y4);
-                    tile[lane][s2 - 3] = (OutT)y4;
+                    wb[s2 - 3] = (OutT)y4;
+                    tail[s2 - 3] = (OutT)y4;
                 }
                 p1 = n1;
                 p2 = n2;
@@ -233,31 +299,16 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
             continue;
         }
         wave_sync();
-        if (fits32 && full_rows && t0 + TB <= N) {
-            // whole tile inside the matrix: one 32-bit offset add per store, no checks
-            uint32_t boff = (uint32_t)((((size_t)(c0 + srow) * (size_t)N) * ROWMUL + (size_t)(t0 + scol)) * sizeof(OutT));
-            // all LDS reads first (distinct registers), then the stores: no load-use wait per row
-            OutT vals[64 / ROWS_PER_STORE];
+        store_window(t0, fits32 && full_rows && t0 > t_begin && t0 + TB <= t_end);
+        wave_sync();
+        // the tile's last d_lane samples in front of the row, for the next window (no other lane writes this row)
+        if (lagged) {
 #pragma unroll
-            for (int q = 0; q < 64 / ROWS_PER_STORE; ++q) vals[q] = tile[q * ROWS_PER_STORE + srow][scol];
-#pragma unroll
-            for (int q = 0; q < 64 / ROWS_PER_STORE; ++q) {
-                *reinterpret_cast<OutT*>(obase + boff) = vals[q];
-                boff += rstep;
-            }
-        } else {
-            const int64_t t = t0 + scol;
-            if (t < N) {
-                OutT* o = reinterpret_cast<OutT*>(obase);
-#pragma unroll 8
-                for (int r = 0; r < 64; r += ROWS_PER_STORE) {
-                    const int row = r + srow;
-                    if (c0 + row < C) o[(size_t)(c0 + row) * (size_t)N * ROWMUL + (size_t)t] = tile[row][scol];
-                }
-            }
+            for (int j = 0; j < TB; ++j) *carry[j] = tail[j];
         }
         wave_sync();
     }
+    if constexpr (MODE != 1) store_window(t_begin + (t_end - t_begin + TB - 1) / TB * TB, false);   // the lagging rest
     if constexpr (MODE == 1) {
         double* e = sp.states + ((size_t)unit * K + seg) * 8 * 64 + lane;
         e[0] = z10, e[64] = z11, e[128] = z20, e[192] = z21, e[256] = z30, e[320] = z31, e[384] = z40, e[448] = z41;
@@ -276,11 +327,11 @@ __global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_fi
                                                        SplitArgs sp) {
     static_assert(MODE == 0 || A2ZERO, "the time-split and queue paths use the direct-form-II kernel");
     constexpr int WPB = waves_per_block<OutT, MODE>();
-    __shared__ OutT tiles[WPB][64][TB + 1];
-    __shared__ double xss[WPB][TB];
+    __shared__ OutT tiles[WPB][64][TileGeo<OutT>::PITCH];
+    __shared__ double xss[WPB][TileGeo<OutT>::TB];
     __shared__ double msh[MODE == 2 ? WPB : 1][MODE == 2 ? 64 : 1][64];   // M of this wave's channels, [entry][lane]
     const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (tells the compiler it is wave-uniform)
     if constexpr (MODE == 3) {
         for (;;) {
             int t = 0;
@@ -288,7 +339,7 @@ __global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_fi
             t = __builtin_amdgcn_readfirstlane(t);
             if (t >= units) return;
             filterbank_unit<WaveT, OutT, A2ZERO, MODE>(wave, offsets, coefs, C, groups, out, alt, alt_off, sp, sp.order[t], 0,
-                                                       lane, wid, tiles[wid], xss[wid], msh[0]);
+                                                       lane, tiles[wid], xss[wid], msh[0]);
         }
     } else {
         const int useg = blockIdx.x * WPB + wid;          // (utterance, group of 64 channels[, segment])
@@ -296,7 +347,7 @@ __global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_fi
         const int unit = useg / K;
         if (unit >= units) return;                        // whole wave: the waves of a workgroup never meet at a barrier
         filterbank_unit<WaveT, OutT, A2ZERO, MODE>(wave, offsets, coefs, C, groups, out, alt, alt_off, sp, unit,
-                                                   useg - unit * K, lane, wid, tiles[wid], xss[wid], msh[MODE == 2 ? wid : 0]);
+                                                   useg - unit * K, lane, tiles[wid], xss[wid], msh[MODE == 2 ? wid : 0]);
     }
 }
 
@@ -382,11 +433,11 @@ void transition_power(const double* coef_row, int L, double* M) {
 int split_segments(int units, int64_t nmax, bool f32_out) {
     const char* env = getenv("F2CNN_K1_SPLIT");            // 0 = never, K >= 2 = force K segments
     const int forced = env ? atoi(env) : -1;
-    if (forced == 0 || nmax < 2 * TB) return 1;
+    if (forced == 0 || nmax < 2 * SEG_ALIGN) return 1;
     // (measured: with the float32 hand-off 512 units still gain 10 % from four segments, 0.82 against 0.92 ms; with
     // float64 output, which is bound by its stores, they lose 25 %)
     int K = forced >= 2 ? forced : (units <= (f32_out ? 512 : 256) ? std::min(32, 2048 / std::max(units, 1)) : 1);
-    K = (int)std::min<int64_t>(K, (nmax + 8 * TB - 1) / (8 * TB));   // at least 256 samples per segment
+    K = (int)std::min<int64_t>(K, (nmax + 8 * SEG_ALIGN - 1) / (8 * SEG_ALIGN));   // at least 256 samples per segment
     return std::max(K, 1);
 }
 
@@ -409,7 +460,7 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
         for (int b = 0; b < B; ++b) nmax = std::max(nmax, h_offsets[b + 1] - h_offsets[b]);
         const int K = split_segments(units, nmax, f32_out);
         if (K > 1) {
-            sp.L = (int)(((nmax + K - 1) / K + TB - 1) / TB * TB);
+            sp.L = (int)(((nmax + K - 1) / K + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN);
             sp.K = (int)((nmax + sp.L - 1) / sp.L);
         }
         if (sp.K > 1) {

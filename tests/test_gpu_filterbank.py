@@ -129,3 +129,40 @@ def test_queue_mode_for_ragged_batches():
         assert a.shape == b.shape == (128, len(w))
         np.testing.assert_array_equal(a, b)
     assert chan_relerr(queued[3], orc.erb_filterbank(waves[3], coefs)) <= 1e-9
+
+
+@pytest.mark.parametrize("C", [128, 130])
+@pytest.mark.parametrize("mode", ["plain", "split", "queue"])
+def test_rows_that_do_not_start_on_a_line(C, mode):
+    """Utterance lengths that are not multiples of 16 (32) put most rows of the (C, n) float64 (float32 hand-off) matrix
+    off the 128-byte lines; the kernel then stores every row with its own lag (f2_filterbank.hip). Every element of
+    every row against the oracle, for the plain kernel, the time-split path and the unit queue, with the float64
+    output, the in-slot float32 hand-off (fused call) and the compact float32 rows long utterances hand over."""
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
+    lens = [1599, 1602, 33, 1601, 47, 3, 2050, 97, 1, 33001 if mode != "split" else 4099]
+    waves = [orc.synth_utterance(300 + i, n) for i, n in enumerate(lens)]
+    env = {"plain": {"F2CNN_K1_SPLIT": "0", "F2CNN_K1_QUEUE": "0"}, "split": {"F2CNN_K1_SPLIT": "3"},
+           "queue": {"F2CNN_K1_SPLIT": "0", "F2CNN_K1_QUEUE": "1"}}[mode]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        gfb = filters.erb_filterbank_batch(waves, coefs)
+        # fused call: float32 hand-off (in the rows' own slots up to 32768 samples, compact scratch rows beyond)
+        flat = np.concatenate(waves)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        envs = np.full(C * int(off[-1]), np.nan)
+        ctx.filterbank_envelope_fused(flat, _lib.WAVE_I16, off, coefs, len(lens), C, False, 0.0, _lib.FFT_F32, envs, None,
+                                      _lib.MEM_HOST)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    for i, (w, g) in enumerate(zip(waves, gfb)):
+        ref = orc.erb_filterbank(w, coefs)
+        assert g.shape == ref.shape
+        assert chan_relerr(g, ref) <= 1e-9, (mode, i)
+        e = envs[C * off[i]:C * off[i + 1]].reshape(C, len(w))
+        assert chan_relerr(e, orc.extract_envelope_from_matrix(ref, False, 0)) <= TOL, (mode, i)

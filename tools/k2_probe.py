@@ -26,3 +26,14 @@ timeit("env f64-in nolpf  out-of-place", lambda: ctx.envelope_batch(d_a, off, B,
 timeit("fused lpf50", lambda: ctx.filterbank_envelope_fused(d_wave, 0, off, coefs, B, C, True, 50.0, 0, d_b, None, 1))
 timeit("fused nolpf", lambda: ctx.filterbank_envelope_fused(d_wave, 0, off, coefs, B, C, False, 0.0, 0, d_b, None, 1))
 timeit("fused lpf50 f64fft", lambda: ctx.filterbank_envelope_fused(d_wave, 0, off, coefs, B, C, True, 50.0, 1, d_b, None, 1))
+# correctness of whatever library is loaded: three rows of the fused output against the oracle
+sys.path.insert(0, "/root/repo/oracle")
+import f2cnn_oracle as orc
+for lpf in (True, False):
+    ctx.filterbank_envelope_fused(d_wave, 0, off, coefs, B, C, lpf, 50.0, 0, d_b, None, 1); ctx.synchronize()
+    worst = 0.0
+    for b, c in ((0, 0), (B // 2, 64), (B - 1, 127)):
+        got = np.empty(N); ctx.d2h(got, d_b + 8 * ((b * C + c) * N))
+        ref = orc.extract_envelope_from_matrix(orc.erb_filterbank(waves[b], coefs[c:c + 1]), lpf, 50)[0]
+        worst = max(worst, float(np.abs(got - ref).max() / np.abs(ref).max()))
+    print("check fused lpf" if lpf else "check fused nolpf", "max rel err", worst, flush=True)
