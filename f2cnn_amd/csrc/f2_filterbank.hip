@@ -28,6 +28,7 @@
 // written per utterance (4*C*N as the float32 hand-off to K2) + 2*N read.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "f2_internal.h"
 
@@ -39,7 +40,11 @@ struct TileGeo {
     static constexpr int RPS = 64 / TB;                      // rows per store instruction
     static constexpr int RQ = 64 / RPS;                      // store instructions per tile; RQ * pitch % TB == 0
     static constexpr int W = 2 * TB;                         // columns of a row in LDS
-    static constexpr int PITCH = W + 1;                      // (odd in words / 2 mod 4: conflict-free column writes)
+    // Row pitch in LDS, chosen per utterance: lane l writes column d_l + s of row l, d_l = (phase + l * pstep) mod TB, so
+    // the 32 lanes of a write group land on banks l * (pitch + pstep) + const: conflict-free when pitch + pstep is odd
+    // (and up to 32-way when it is a multiple of 32). pstep even -> W + 1, pstep odd -> W + 2.
+    static constexpr int PITCH0 = W + 1;
+    static constexpr int PITCH_MAX = W + 2;
 };
 constexpr int SEG_ALIGN = 32;   // host: segment lengths of the time-split path, a multiple of every tile size
 // Wavefronts per workgroup. The waves of a workgroup are independent (own utterance/channel group, own LDS tile, no
@@ -93,10 +98,10 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
                                                 const double* __restrict__ coefs, int C, int groups,
                                                 double* __restrict__ out, float* __restrict__ alt,
                                                 const int64_t* __restrict__ alt_off, const SplitArgs& sp, int unit, int seg,
-                                                int lane, OutT (*tile)[TileGeo<OutT>::PITCH], double* xs,
+                                                int lane, OutT* tile, double* xs,
                                                 double (*mshw)[64]) {
     using G = TileGeo<OutT>;
-    constexpr int TB = G::TB, RQ = G::RQ, PITCH = G::PITCH;
+    constexpr int TB = G::TB, RQ = G::RQ;
     const int K = (MODE == 1 || MODE == 2) ? sp.K : 1;
     const int b = unit / groups;
     const int c0 = (unit % groups) * 64;
@@ -168,31 +173,47 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
     const int phase_c0 = (int)((reinterpret_cast<uintptr_t>(obase) / sizeof(OutT) + (uint64_t)c0 * (uint64_t)pitch) & (TB - 1));
     const int d_lane = (phase_c0 + lane * pstep) & (TB - 1);
     const bool lagged = (pstep | phase_c0) != 0;              // wave-uniform; false: every row starts on a line, d = 0
-    OutT* const wb = &tile[lane][d_lane];
-    const OutT* const rb = &tile[srow * RQ][scol];            // row q + srow*RQ of store q: rb + q*PITCH
+    const int lpitch = G::PITCH0 + (pstep & 1);                // LDS row pitch of this utterance (TileGeo)
+    OutT* const wb = tile + lane * lpitch + d_lane;
+    const OutT* const rb = tile + srow * RQ * lpitch + scol;   // row q + srow*RQ of store q: rb + q*lpitch
     [[maybe_unused]] OutT* carry[TB];                         // where sample j of a tile waits for the next window
     if constexpr (MODE != 1) {
 #pragma unroll
-        for (int j = 0; j < TB; ++j) carry[j] = &tile[lane][(d_lane + j + TB) & (2 * TB - 1)];
+        for (int j = 0; j < TB; ++j) carry[j] = tile + lane * lpitch + ((d_lane + j + TB) & (2 * TB - 1));
     }
     OutT* const orow = reinterpret_cast<OutT*>(obase) + (size_t)c0 * (size_t)pitch;
     const uint32_t voff = (uint32_t)(((size_t)(srow * RQ) * (size_t)pitch + (size_t)scol) * sizeof(OutT));   // (fits32)
     // Samples [t0 - d, t0 - d + TB) of every row, d the row's lag; `fast`: all of them inside [t_begin, t_end), all 64
     // rows exist, offsets fit 32 bits - wave-uniform row base + fixed lane offset, no checks.
-    auto store_window = [&](int64_t t0, bool fast) {
-        int dq = phase_c0;
+    auto store_window_p = [&](int64_t t0, bool fast, auto lp) {
+        constexpr int PITCH = decltype(lp)::value;
         if (fast) {
             OutT vals[RQ];   // all LDS reads first (distinct registers), then the stores: no load-use wait per row
 #pragma unroll
             for (int q = 0; q < RQ; ++q) vals[q] = rb[q * PITCH];
-            const char* base = reinterpret_cast<const char*>(orow + t0);
+            if (!lagged) {
+                // every row on a line: one lane pointer stepped by the row pitch
+                char* p = reinterpret_cast<char*>(orow + t0) + voff;
+                const int64_t rstep = pitch * (int64_t)sizeof(OutT);
 #pragma unroll
-            for (int q = 0; q < RQ; ++q) {
-                char* p = const_cast<char*>(base) + ((int64_t)q * pitch - dq) * (int64_t)sizeof(OutT);
-                *reinterpret_cast<OutT*>(p + voff) = vals[q];
-                dq = (dq + pstep) & (TB - 1);
+                for (int q = 0; q < RQ; ++q) {
+                    *reinterpret_cast<OutT*>(p) = vals[q];
+                    p += rstep;
+                }
+            } else {
+                // row q starts dq samples early: wave-uniform row pointer (scalar unit) + the fixed lane offset
+                const char* rowp = reinterpret_cast<const char*>(orow + t0);
+                const int64_t rstep = pitch * (int64_t)sizeof(OutT);
+                int dq = phase_c0;
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) {
+                    *reinterpret_cast<OutT*>(const_cast<char*>(rowp) - dq * (int)sizeof(OutT) + voff) = vals[q];
+                    rowp += rstep;
+                    dq = (dq + pstep) & (TB - 1);
+                }
             }
         } else {
+            int dq = phase_c0;
 #pragma unroll 8
             for (int q = 0; q < RQ; ++q) {
                 const int row = q + srow * RQ;
@@ -201,6 +222,10 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
                 dq = (dq + pstep) & (TB - 1);
             }
         }
+    };
+    auto store_window = [&](int64_t t0, bool fast) {
+        if (pstep & 1) store_window_p(t0, fast, std::integral_constant<int, G::PITCH0 + 1>{});
+        else store_window_p(t0, fast, std::integral_constant<int, G::PITCH0>{});
     };
 
     // The input block is fetched one block ahead: vmcnt retires in issue order (stores included), so a load
@@ -327,7 +352,7 @@ __global__ __launch_bounds__((64 * waves_per_block<OutT, MODE>())) void k_erb_fi
                                                        SplitArgs sp) {
     static_assert(MODE == 0 || A2ZERO, "the time-split and queue paths use the direct-form-II kernel");
     constexpr int WPB = waves_per_block<OutT, MODE>();
-    __shared__ OutT tiles[WPB][64][TileGeo<OutT>::PITCH];
+    __shared__ OutT tiles[WPB][64 * TileGeo<OutT>::PITCH_MAX];
     __shared__ double xss[WPB][TileGeo<OutT>::TB];
     __shared__ double msh[MODE == 2 ? WPB : 1][MODE == 2 ? 64 : 1][64];   // M of this wave's channels, [entry][lane]
     const int lane = threadIdx.x & 63;
