@@ -166,3 +166,25 @@ def test_rows_that_do_not_start_on_a_line(C, mode):
         assert chan_relerr(g, ref) <= 1e-9, (mode, i)
         e = envs[C * off[i]:C * off[i + 1]].reshape(C, len(w))
         assert chan_relerr(e, orc.extract_envelope_from_matrix(ref, False, 0)) <= TOL, (mode, i)
+
+
+@pytest.mark.parametrize("C,N", [(128, 4001), (70, 16000), (8, 97)])
+def test_general_coefficient_tables(C, N):
+    """erb_filterbank takes any (C, 10) table, like the reference (filters.py:228-237 hands the columns to lfilter as
+    they are): numerators with a z^-2 term and B0 != 1 run the transposed-direct-form-II kernel instead of the
+    three-FMA sections make_erb_filters' tables allow; single utterance, a ragged batch and float64 samples."""
+    rng = np.random.default_rng(C + N)
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100)).copy()
+    coefs[:, 5] = coefs[:, 0] * rng.uniform(-0.5, 0.5, C)          # A2
+    scale = rng.uniform(0.5, 2.0, C)                                # B0 (lfilter normalises by it)
+    coefs[:, 6:9] *= scale[:, None]
+    wave = orc.synth_utterance(77 + C, N)
+    ref = orc.erb_filterbank(wave, coefs)
+    assert chan_relerr(filters.erb_filterbank(wave, coefs), ref) <= 1e-9
+    noisy = wave.astype(np.float64) + rng.standard_normal(N)
+    assert chan_relerr(filters.erb_filterbank(noisy, coefs), orc.erb_filterbank(noisy, coefs)) <= 1e-9
+    waves = [wave[:n] for n in (N, 33, N // 2 + 1, 1)]
+    for w, g in zip(waves, filters.erb_filterbank_batch(waves, coefs)):
+        assert chan_relerr(g, orc.erb_filterbank(w, coefs)) <= 1e-9
+    if N <= 200:
+        assert chan_relerr(orc.erb_filterbank_loops(wave, coefs), ref) <= 1e-12
