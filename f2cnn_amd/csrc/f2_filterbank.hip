@@ -52,10 +52,10 @@ constexpr int SEG_ALIGN = 32;   // host: segment lengths of the time-split path,
 // one-wave workgroups the 2000 waves of the benchmark batch land unevenly (some SIMDs run three, others one) and the
 // kernel takes as long as the fullest SIMD.
 #ifndef F2_K1_WAVES_F32
-#define F2_K1_WAVES_F32 4     // float32 hand-off tiles: 4 x 16.6 KB of LDS
+#define F2_K1_WAVES_F32 4     // float32 hand-off tiles: 4 x 16.9 KB of LDS
 #endif
 #ifndef F2_K1_WAVES_F64
-#define F2_K1_WAVES_F64 2     // float64 output tiles: 2 x 16.9 KB (the store-bound variant gains nothing beyond two)
+#define F2_K1_WAVES_F64 2     // float64 output tiles: 2 x 17.4 KB (the store-bound variant gains nothing beyond two)
 #endif
 // (MODE 2 of the time-split path keeps a 32 KB matrix table per wave in LDS: two waves per workgroup)
 template <typename OutT, int MODE = 0>
@@ -459,9 +459,9 @@ int split_segments(int units, int64_t nmax, bool f32_out) {
     const char* env = getenv("F2CNN_K1_SPLIT");            // 0 = never, K >= 2 = force K segments
     const int forced = env ? atoi(env) : -1;
     if (forced == 0 || nmax < 2 * SEG_ALIGN) return 1;
-    // (measured: with the float32 hand-off 512 units still gain 10 % from four segments, 0.82 against 0.92 ms; with
-    // float64 output, which is bound by its stores, they lose 25 %)
-    int K = forced >= 2 ? forced : (units <= (f32_out ? 512 : 256) ? std::min(32, 2048 / std::max(units, 1)) : 1);
+    // (measured, tools/k1_small_batch.py: with the float32 hand-off 192 units gain 1.7x, 384 units break even, 512 lose
+    // 15 %; with float64 output, which is bound by its stores, 512 units lose 25 %)
+    int K = forced >= 2 ? forced : (units <= (f32_out ? 320 : 256) ? std::min(32, 2048 / std::max(units, 1)) : 1);
     K = (int)std::min<int64_t>(K, (nmax + 8 * SEG_ALIGN - 1) / (8 * SEG_ALIGN));   // at least 256 samples per segment
     return std::max(K, 1);
 }
