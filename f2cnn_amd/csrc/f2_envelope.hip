@@ -146,6 +146,25 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
         else load_row(x, std::true_type{});
     }
     F2_STAMP(1);
+#ifdef F2_FUSE_PROBE
+    // Timing probe (results wrong by ~1e-30): the float64 work a row-parallel filterbank inside this workgroup would
+    // add - F2_FUSE_PROBE FMAs per thread in eight independent chains - to see how it co-schedules with the
+    // transforms of the other workgroup on the CU. Use with -DF2_KO_LOAD.
+    {
+        double acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = (double)v[q].re;
+        const double ca = 0.999999 + 1e-9 * tid, cb = 1e-7;
+        for (int it = 0; it < F2_FUSE_PROBE / 8; ++it) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = fma(acc[q], ca, cb);
+        }
+        double sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += acc[q];
+        v[0].re += (F)(sum * 1e-30);
+    }
+#endif
     // 2. forward transform (first pass straight from the registers)
     constexpr bool T0R = derive_tw0<F, LOG2H>();
     fft_all<F, LOG2H, false, PT, NT, T0R>(lds, tw, twl, tid, v);
