@@ -158,3 +158,25 @@ def test_cfg5_corpus_sharded_over_two_ranks(workload):
         wave = bench.synth_utterance(2029 + u, int(all_lens[u]))
         ref = orc.extract_envelope_from_matrix(orc.erb_filterbank(wave, coefs[rows]), True, 50)
         assert chan_relerr(one[u][rows], ref) <= 1e-5, (workload, u)
+
+
+def test_maximum_row_length():
+    """The longest rows the library takes (2^22 samples = 4.4 min of audio; limit of the global-memory transform) and the
+    first length beyond: a 128-channel filterbank of such an utterance is 4.3 GB, past the 32-bit byte offsets the store
+    phase of K1 normally uses (its 64-bit path), and the envelope runs the radix-16 passes over global memory."""
+    from f2cnn_amd.scripts.processing.EnvelopeExtraction import ExtractEnvelopeFromMatrix
+    nmax = 1 << 22
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
+    wave = bench.synth_utterance(4242, nmax)
+    gfb = filters.erb_filterbank(wave, coefs)
+    assert gfb.shape == (C, nmax)
+    rows = [0, 63, 64, 127]
+    ref = orc.erb_filterbank(wave, coefs[rows])
+    assert chan_relerr(gfb[rows], ref) <= 1e-9
+    assert np.isfinite(gfb[:, ::4099]).all() and np.abs(gfb[:, -4096:]).max(axis=1).min() > 0   # every row written to its end
+    for lpf in (False, True):
+        env = ExtractEnvelopeFromMatrix(gfb[rows], lpf, 50)
+        assert chan_relerr(env, orc.extract_envelope_from_matrix(ref, lpf, 50)) <= 1e-5
+    del gfb
+    with pytest.raises(_lib.F2Error, match="not supported"):
+        ExtractEnvelopeFromMatrix(np.ones((1, nmax + 1)), False)
