@@ -71,6 +71,7 @@ __device__ __forceinline__ void sub_row(cpx<float>* lds, const cpx<float>* __res
                                         const cpx<float>* __restrict__ vo, int tid, cpx<float> (&v)[Geo<LOG2S>::PT]) {
     constexpr int HS = Geo<LOG2S>::HS, NT = Geo<LOG2S>::NT, PT = Geo<LOG2S>::PT;
     constexpr bool T0R = derive_tw0<float, LOG2S>();
+    asm volatile("" : "+v"(tid));   // (nothing derived from the thread index outside this sub-row is kept alive through it)
     fft_all<float, LOG2S, false, PT, NT, T0R>(lds, tw, twl, tid, v);       // spectrum at lds[cpad(k)]
     const float sc = 1.0f / (float)HS;
     if constexpr (!ODD) {
@@ -157,7 +158,8 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
     for (int j0 = 0; j0 < R0; j0 += LOADCHUNK) {
 #pragma unroll
         for (int j = j0; j < j0 + LOADCHUNK; ++j) {
-            const int m = tid + j * NB0;
+            int m = tid + j * NB0;
+            asm volatile("" : "+v"(m));       // (addresses are recomputed per stage, not held in registers across the transforms)
             const cpx<float> z0 = load_pair<T>(x, n, 2 * m), z1 = load_pair<T>(x, n, 2 * (m + HS));
             v[j] = z0 + z1;
             park_b[m] = cmul(z0 - z1, P.tx[m]);
@@ -166,9 +168,17 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
     }
     sub_row<LOG2S, false>(lds, tw, twl, P.vo, tid, v);
 #pragma unroll
-    for (int j = 0; j < R0; ++j) park_e[tid + j * NB0] = v[brev<R0>(j)];
+    for (int j = 0; j < R0; ++j) {
+        int m = tid + j * NB0;
+        asm volatile("" : "+v"(m));
+        park_e[m] = v[brev<R0>(j)];
+    }
 #pragma unroll
-    for (int j = 0; j < R0; ++j) v[j] = park_b[tid + j * NB0];       // this thread's own stores: no synchronisation
+    for (int j = 0; j < R0; ++j) {
+        int m = tid + j * NB0;
+        asm volatile("" : "+v"(m));
+        v[j] = park_b[m];       // this thread's own stores: no synchronisation
+    }
     sub_row<LOG2S, true>(lds, tw, twl, P.vo, tid, v);
 
     // last radix-2 stage + magnitude: lower half of the row from E + T O, upper half from E - T O. The lower half's

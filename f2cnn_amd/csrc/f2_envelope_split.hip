@@ -129,9 +129,11 @@ __global__ __launch_bounds__(2 * NTH, 4) void k_split_mid(SplitParams P) {
 #pragma unroll
     for (int j0 = 0; j0 < R0; j0 += 4) {
         cpx<float> zk[4], zm[4], r2[4];
+        int tp = t;
+        asm volatile("" : "+v"(tp));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int k2 = t + (j0 + q) * NB0;
+            const int k2 = tp + (j0 + q) * NB0;
             const int km = ka == 0 ? ((H2 - k2) & (H2 - 1)) : H2 - 1 - k2;
             zk[q] = own[cpad(k2)];
             zm[q] = partner[cpad(km)];
@@ -148,8 +150,10 @@ __global__ __launch_bounds__(2 * NTH, 4) void k_split_mid(SplitParams P) {
     __syncthreads();   // all reads of both halves' spectra precede the next transform's LDS writes
     fft_regs_to_regs<float, LOG2H2, PT, NTH, T0R>(own, P.tw12, twl, t, v);   // point t + j*NB0 in v[brev<R0>(j)]
     if (half == 0 || !self) {
+        int ts = t;
+        asm volatile("" : "+v"(ts));   // (the 16 addresses are formed again here, not held through both transforms)
 #pragma unroll
-        for (int j = 0; j < R0; ++j) A[t + j * NB0] = v[brev<R0>(j)];
+        for (int j = 0; j < R0; ++j) A[ts + j * NB0] = v[brev<R0>(j)];
     }
 }
 
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void k_split_last(SplitParams P) {
 // 2*LNT*LNB = 16384 samples per step
 constexpr int LNT = 512, LNB = 16;
 template <int H1>
-__global__ __launch_bounds__(LNT, 4) void k_split_lowpass(SplitParams P) {
+__global__ __launch_bounds__(LNT, 2) void k_split_lowpass(SplitParams P) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[lowpass_lds_bytes<float, LNT, LNB>()];
     __shared__ float e_last;
     const int tid = threadIdx.x;
