@@ -55,7 +55,22 @@ struct PairParams {
     const int64_t* x32_off;
     const cpx<float>* tx;      // [HS]   exp(-2 pi i m / H) = (cos, -sin)(pi m / HS)
     const cpx<float>* vo;      // [HS/2] (cos, -sin)(pi (2j+1) / H): pair-step angles of the odd sub-row
+    unsigned long long* stamps;   // diagnostic build only (-DF2_STAMPS)
 };
+
+// Diagnostic build only (-DF2_STAMPS): wave 0 of every workgroup records s_memrealtime (100 MHz) at the phase boundaries.
+#ifdef F2_STAMPS
+#define F2_PSTAMP(k)                                         \
+    do {                                                     \
+        __builtin_amdgcn_sched_barrier(0);                   \
+        pst[k] = __builtin_amdgcn_s_memrealtime();             \
+        __builtin_amdgcn_sched_barrier(0);                   \
+    } while (0)
+#else
+#define F2_PSTAMP(k) \
+    do {             \
+    } while (0)
+#endif
 
 // samples i0, i0 + 1 (i0 even) of a row of n samples as floats, 0 beyond the end
 template <typename T>
@@ -154,6 +169,10 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
     // load + first radix-2 stage; point j of this thread is m = tid + j * NB0. A few points at a time: with all 16
     // in flight the loads alone would hold 96 registers.
     cpx<float> v[PT];
+#ifdef F2_STAMPS
+    unsigned long long pst[8] = {0};
+#endif
+    F2_PSTAMP(0);
 #pragma unroll
     for (int j0 = 0; j0 < R0; j0 += LOADCHUNK) {
 #pragma unroll
@@ -166,7 +185,9 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    F2_PSTAMP(1);
     sub_row<LOG2S, false>(lds, tw, twl, P.vo, tid, v);
+    F2_PSTAMP(2);
 #pragma unroll
     for (int j = 0; j < R0; ++j) {
         int m = tid + j * NB0;
@@ -179,12 +200,16 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
         asm volatile("" : "+v"(m));
         v[j] = park_b[m];       // this thread's own stores: no synchronisation
     }
+    F2_PSTAMP(3);
     sub_row<LOG2S, true>(lds, tw, twl, P.vo, tid, v);
+    F2_PSTAMP(4);
 
     // last radix-2 stage + magnitude: lower half of the row from E + T O, upper half from E - T O. The lower half's
     // envelopes stay in registers until every thread has read its parked points (they overwrite the parking area);
     // the upper half's positions lie beyond it and are written at once - final float64 values without low-pass, else
     // the float pair at the start of its own 16-byte output position, where it waits for the second low-pass segment.
+    // (Packing those pairs into whole lines at the start of the upper half's region instead: 8 % faster for n = 65536,
+    // 2-3 % slower for n <= 40000, 1.7 % slower on the U[1 s, 4 s] corpus: not kept.)
     float er[R0], ei[R0];
 #pragma unroll
     for (int j0 = 0; j0 < R0; j0 += 4) {
@@ -210,6 +235,7 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
         __builtin_amdgcn_sched_barrier(0);
     }
     if (tid == NT - 1) *e_mid_p = ei[R0 - 1];   // envelope sample 2 HS - 1: e[n-1] entering the upper half's low-pass
+    F2_PSTAMP(5);
     __syncthreads();   // every read of the parked sub-rows (and the last LDS reads) precedes the stores over them
     if (!P.lpf) {
 #pragma unroll
@@ -219,6 +245,7 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
         return;
     }
     const double ycarry = lowpass_pairs_store<float, NT, R0>(er, ei, P.a1, P.b0, smem, y, 2 * HS, tid);
+    F2_PSTAMP(6);
 #pragma unroll
     for (int j = 0; j < R0; ++j) {
         const int i1 = 2 * (tid + j * NB0 + HS);
@@ -228,6 +255,11 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
     }
     __syncthreads();   // the scan's last LDS reads precede the next segment's writes
     lowpass_pairs_store<float, NT, R0>(er, ei, P.a1, P.b0, smem, y + 2 * HS, n - 2 * HS, tid, ycarry, *e_mid_p);
+#ifdef F2_STAMPS
+    F2_PSTAMP(7);
+    if (tid == 0 && P.stamps)
+        for (int k = 0; k < 8; ++k) P.stamps[(size_t)blockIdx.x * 8 + k] = pst[k];
+#endif
 }
 
 template <int LOG2S>
@@ -276,6 +308,13 @@ int launch_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* 
     P.tx = (const cpx<float>*)tables.ptr;
     P.vo = P.tx + HS;
     P.ulist = (const int*)list.ptr;
+    P.stamps = nullptr;
+#ifdef F2_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    const size_t nstamp = (size_t)nutt * C * 8;
+    if (!d_stamps) F2_HIP(ctx, hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 8 * 128 * 2048));
+    if (nstamp <= (size_t)8 * 128 * 2048) P.stamps = d_stamps;
+#endif
     const dim3 grid((unsigned)((size_t)nutt * C)), block(NT);
     const cpx<float>* tw = (const cpx<float>*)ctx->tw[0][LOG2S].ptr;
     F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
@@ -285,6 +324,22 @@ int launch_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* 
         hipLaunchKernelGGL((k_envelope_pair<LOG2S, double>), grid, block, 0, ctx->stream, P, tw);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_ENVELOPE));
+#ifdef F2_STAMPS
+    if (P.stamps) {
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<unsigned long long> h(nstamp);
+        F2_HIP(ctx, hipMemcpy(h.data(), d_stamps, sizeof(unsigned long long) * nstamp, hipMemcpyDeviceToHost));
+        double acc[8] = {0};
+        const size_t rows = (size_t)nutt * C;
+        for (size_t r = 0; r < rows; ++r)
+            for (int k = 1; k < 8; ++k) acc[k] += (double)(h[r * 8 + k] - h[r * 8 + k - 1]);
+        static const char* names[8] = {"", "load+radix2", "even sub-row", "park E/fetch b", "odd sub-row", "last stage+magnitude",
+                                       "barrier+lpf lower", "lpf upper"};
+        fprintf(stderr, "[pair stamps] mean 10 ns ticks per workgroup:");
+        for (int k = 1; k < 8; ++k) fprintf(stderr, " %s=%.0f", names[k], acc[k] / rows);
+        fprintf(stderr, "\n");
+    }
+#endif
     return F2_OK;
 }
 
