@@ -47,6 +47,9 @@ typedef enum {
  * contexts so that batch k's device-to-host copy runs beside batch k+1's host-to-device copy and kernels.
  * Accepted by f2_erb_filterbank_batch, f2_envelope_batch and f2_filterbank_envelope_fused. */
 enum { F2_MEM_HOST = 0, F2_MEM_DEVICE = 1, F2_MEM_HOST_ASYNC = 2 };
+/* Alignment: device buffers need the natural alignment of their element type only (hipMalloc gives far more).
+ * Utterance lengths are arbitrary: rows of the (C, n) matrices start wherever C-order puts them, and the kernels keep
+ * their stores on whole 128-byte lines and their loads wide for any n (no padding of n, no pitch parameter). */
 enum { F2_WAVE_I16 = 0, F2_WAVE_F64 = 1 };
 /* arithmetic of the Hilbert FFT: F2_FFT_F32 (default; 3.6e-7 max-norm error) or
  * F2_FFT_F64 (reference-grade, slower). The IIR recurrences are float64 in both. */
