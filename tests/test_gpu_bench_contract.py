@@ -44,7 +44,8 @@ def test_default_workload_line():
     assert d["kernels"]["k_erb_filterbank"]["f64_TFLOPps"] > 0
     # the other configurations ride along in the default single-GPU line
     b = d["blocks"]
-    assert set(b) >= {"cfg3_fft_f64", "cfg5", "cfg5_ragged", "cfg4", "end_to_end"}
+    assert set(b) >= {"cfg3_fft_f64", "cfg5", "cfg5_ragged", "cfg1", "cfg4", "end_to_end"}
+    assert 0 < b["cfg1"]["latency_us"] < 2000
     assert b["cfg3_fft_f64"]["value"] > 0 and b["cfg5"]["scaling"] == "strong" and b["cfg5_ragged"]["value"] > 0
     assert 0 < b["cfg4"]["cnn"]["frac"] < 1 and b["cfg4"]["cpu_baseline"]["value"] > 0
     e = b["end_to_end"]
