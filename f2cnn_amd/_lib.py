@@ -17,7 +17,7 @@ F2_OK, F2_ERR_INVALID, F2_ERR_HIP, F2_ERR_UNSUPPORTED, F2_ERR_NOMEM, F2_ERR_NONP
 MEM_HOST, MEM_DEVICE, MEM_HOST_ASYNC = 0, 1, 2
 WAVE_I16, WAVE_F64 = 0, 1
 FFT_F32, FFT_F64 = 0, 1
-K_COUNT = 5
+K_COUNT = 7
 
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _P = C.POINTER
@@ -32,6 +32,8 @@ SIGNATURES = {
     "f2_ctx_set_stream": (_i, [_vp, _vp]),
     "f2_ctx_get_stream": (_vp, [_vp]),
     "f2_last_error": (C.c_char_p, [_vp]),
+    "f2_ctx_set_option": (_i, [_vp, C.c_char_p, _d]),
+    "f2_ctx_get_option": (_i, [_vp, C.c_char_p, _P(_d)]),
     "f2_dev_malloc": (_i, [_vp, C.c_size_t, _P(_vp)]),
     "f2_dev_free": (_i, [_vp, _vp]),
     "f2_dev_memset": (_i, [_vp, _vp, _i, C.c_size_t]),
@@ -168,6 +170,33 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self.check(self.lib.f2_ctx_set_stream(self.handle, stream_ptr))
+
+    def set_option(self, key, value):
+        """Per-context tuning switch (include/f2cnn_hip.h: f2_ctx_set_option); returns the previous value."""
+        old = self.get_option(key)
+        self.check(self.lib.f2_ctx_set_option(self.handle, key.encode(), float(value)))
+        return old
+
+    def get_option(self, key):
+        v = _d()
+        self.check(self.lib.f2_ctx_get_option(self.handle, key.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kv):
+        """Context manager: set the given options, restore the previous values on exit."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                self_inner.old = {k: ctx.set_option(k, v) for k, v in kv.items()}
+                return ctx
+
+            def __exit__(self_inner, *exc):
+                for k, v in self_inner.old.items():
+                    ctx.set_option(k, v)
+                return False
+
+        return _Scope()
 
     def malloc(self, nbytes):
         p = _vp()

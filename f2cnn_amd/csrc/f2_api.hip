@@ -67,7 +67,7 @@ int f2_prof_end(f2_ctx* ctx, int kernel_id) {
 
 extern "C" {
 
-int f2_version(void) { return 102; }   // 101: f2_eval_batch; 102: f2_host_alloc, F2_MEM_HOST_ASYNC
+int f2_version(void) { return 103; }   // 101: f2_eval_batch; 102: f2_host_alloc, F2_MEM_HOST_ASYNC; 103: f2_ctx_set_option
 
 int f2_device_count(int* count) {
     if (!count) return f2_fail(nullptr, F2_ERR_INVALID, "count is NULL");
@@ -155,6 +155,14 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     if (ctx->k1_order.ptr) (void)hipFree(ctx->k1_order.ptr);
     if (ctx->handoff.ptr) (void)hipFree(ctx->handoff.ptr);
     if (ctx->handoff_off.ptr) (void)hipFree(ctx->handoff_off.ptr);
+    for (auto& t : ctx->spec_tabs)
+        for (f2_scratch* sc : {&t.hu, &t.e, &t.lgroup})
+            if (sc->ptr) (void)hipFree(sc->ptr);
+    for (f2_scratch* sc : {&ctx->spec_x, &ctx->spec_rho, &ctx->spec_meta, &ctx->spec_uflag})
+        if (sc->ptr) (void)hipFree(sc->ptr);
+    for (auto& prec : ctx->tw_sp)
+        for (f2_scratch& sc : prec)
+            if (sc.ptr) (void)hipFree(sc.ptr);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -184,6 +192,66 @@ int f2_ctx_set_stream(f2_ctx* ctx, void* hip_stream) {
 void* f2_ctx_get_stream(f2_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 const char* f2_last_error(f2_ctx* ctx) { return ctx ? ctx->err : g_f2_err; }
+
+namespace {
+struct opt_entry {
+    const char* key;
+    int f2_ctx::*ifield;
+    float f2_ctx::*ffield;
+    double lo, hi;
+};
+const opt_entry kOptions[] = {
+    {"spectral", &f2_ctx::opt_spectral, nullptr, 0, 1},
+    {"spectral_tol", nullptr, &f2_ctx::opt_spectral_tol, 0, 1},
+    {"k1_split", &f2_ctx::opt_k1_split, nullptr, -1, 64},
+    {"k1_queue", &f2_ctx::opt_k1_queue, nullptr, -1, 1},
+    {"k1_qwaves", &f2_ctx::opt_k1_qwaves, nullptr, 0, 1 << 20},
+    {"env_pair", &f2_ctx::opt_env_pair, nullptr, 0, 1},
+    {"env_plan4", &f2_ctx::opt_env_plan4, nullptr, 0, 1},
+};
+const opt_entry* find_option(const char* key) {
+    if (!key) return nullptr;
+    for (const opt_entry& e : kOptions)
+        if (strcmp(e.key, key) == 0) return &e;
+    return nullptr;
+}
+}  // namespace
+
+int f2_ctx_set_option(f2_ctx* ctx, const char* key, double value) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    const opt_entry* e = find_option(key);
+    F2_CHECK(ctx, e, F2_ERR_INVALID, "unknown option '%s'", key ? key : "(null)");
+    F2_CHECK(ctx, value >= e->lo && value <= e->hi, F2_ERR_INVALID, "option %s: %g outside [%g, %g]", key, value, e->lo, e->hi);
+    if (e->ifield) {
+        F2_CHECK(ctx, value == (double)(int)value, F2_ERR_INVALID, "option %s takes an integer", key);
+        ctx->*(e->ifield) = (int)value;
+    } else {
+        ctx->*(e->ffield) = (float)value;
+    }
+    return F2_OK;
+}
+
+int f2_ctx_get_option(f2_ctx* ctx, const char* key, double* value) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    if (key && value && strcmp(key, "spectral_flagged") == 0) {
+        // read-only: utterances of the last fused call that the spectral kernel's accuracy guard sent back to the
+        // filterbank kernel + envelope kernel (waits for the stream)
+        *value = 0;
+        const size_t B = ctx->spec_last_B;
+        if (B == 0 || !ctx->spec_uflag.ptr || ctx->spec_meta_host.size() < B) return F2_OK;
+        std::vector<int> flags(B);
+        F2_HIP(ctx, hipMemcpyAsync(flags.data(), ctx->spec_uflag.ptr, sizeof(int) * B, hipMemcpyDeviceToHost, ctx->stream));
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int cnt = 0;
+        for (size_t b = 0; b < B; ++b) cnt += (flags[b] != 0 && ctx->spec_meta_host[b] == 0);
+        *value = cnt;
+        return F2_OK;
+    }
+    const opt_entry* e = find_option(key);
+    F2_CHECK(ctx, e && value, F2_ERR_INVALID, "unknown option '%s'", key ? key : "(null)");
+    *value = e->ifield ? (double)(ctx->*(e->ifield)) : (double)(ctx->*(e->ffield));
+    return F2_OK;
+}
 
 int f2_dev_malloc(f2_ctx* ctx, size_t bytes, void** dptr) {
     F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
@@ -321,7 +389,7 @@ int f2_prof_get(f2_ctx* ctx, int kernel_id, int* launches, float* total_ms) {
 
 const char* f2_prof_kernel_name(int kernel_id) {
     static const char* names[F2_K_COUNT] = {"k_erb_filterbank", "k_envelope", "k_gather_windows", "k_cnn_forward",
-                                            "k_fused_filterbank_envelope"};
+                                            "k_spectral_envelope", "k_utterance_spectrum", "k_tail_state"};
     return kernel_id >= 0 && kernel_id < F2_K_COUNT ? names[kernel_id] : "";
 }
 
@@ -498,17 +566,59 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
         d_env = (double*)ctx->stage_out.ptr;
         d_gfb = gfb_or_null ? (double*)ctx->stage_aux.ptr : nullptr;
     }
-    // Two launches queued back to back on the context's stream, no third buffer and no host round trip.
-    // When the float64 filterbank output is not wanted and the envelope runs its float32 FFT, the filterbank
+    // Spectral path (f2_spectral.hip): utterances it can serve (float FFT, no GFB output wanted, make_erb_filters-shaped
+    // table, 4097..16384 samples with padding to look at) get their envelopes from ONE kernel that never materialises
+    // the filterbank rows. Everything else - and any utterance that kernel's accuracy guard flags on the device - goes
+    // through the filterbank kernel + envelope kernel below, which skip utterances whose flag is 0.
+    const int* d_uflag = nullptr;
+    ctx->spec_last_B = 0;
+    if (ctx->opt_spectral && fft_precision == F2_FFT_F32 && !d_gfb && f2_spectral_supports_coefs(ctx->coefs_host, C, nullptr)) {
+        std::vector<int> meta((size_t)B, 1);
+        std::vector<int> lists[F2_SPECTRAL_MAX_LOG2H + 1];
+        int nspec = 0;
+        for (int b = 0; b < B; ++b) {
+            const int64_t n = offsets[b + 1] - offsets[b];
+            if (!f2_spectral_supports_len(n)) continue;
+            lists[f2_log2_ceil(n) - 1].push_back(b);
+            meta[(size_t)b] = 0;
+            ++nspec;
+        }
+        if (nspec > 0) {
+            size_t pos[F2_SPECTRAL_MAX_LOG2H + 1];
+            for (int l = F2_SPECTRAL_MIN_LOG2H; l <= F2_SPECTRAL_MAX_LOG2H; ++l) {
+                pos[l] = meta.size();
+                meta.insert(meta.end(), lists[l].begin(), lists[l].end());
+            }
+            if (meta != ctx->spec_meta_host) {   // new batch shape (as f2_upload_offsets: the upload waits for the stream)
+                ctx->spec_meta_host.clear();
+                F2_TRY(f2_reserve(ctx, ctx->spec_meta, sizeof(int) * meta.size()));
+                F2_TRY(f2_reserve(ctx, ctx->spec_uflag, sizeof(int) * (size_t)B));
+                F2_HIP(ctx, hipMemcpyAsync(ctx->spec_meta.ptr, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice,
+                                           ctx->stream));
+                F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                ctx->spec_meta_host = meta;
+            }
+            int* uflag = (int*)ctx->spec_uflag.ptr;
+            F2_HIP(ctx, hipMemcpyAsync(uflag, ctx->spec_meta.ptr, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, ctx->stream));
+            for (int l = F2_SPECTRAL_MIN_LOG2H; l <= F2_SPECTRAL_MAX_LOG2H; ++l)
+                F2_TRY(f2_launch_spectral(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, (const double*)ctx->coefs.ptr,
+                                          C, (const int*)ctx->spec_meta.ptr + pos[l], (int)lists[l].size(), l, lpf, cutoff_hz,
+                                          d_env, uflag));
+            d_uflag = uflag;
+            ctx->spec_last_B = (size_t)B;
+        }
+    }
+    // Filterbank kernel + envelope kernel queued back to back on the context's stream, no third buffer and no host
+    // round trip. When the float64 filterbank output is not wanted and the envelope runs its float32 FFT, the filterbank
     // hands its rows over as float32 inside the ENV buffer itself (half the bytes written and read back;
     // the envelope kernel converts to float32 before its FFT anyway, so the result is bit-identical).
     f2_handoff handoff;
     F2_TRY(f2_plan_handoff(ctx, offsets, B, C, fft_precision, d_gfb != nullptr, &handoff));
     double* k1_out = d_gfb ? d_gfb : d_env;
     F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
-                                (const double*)ctx->coefs.ptr, B, C, k1_out, &handoff));
+                                (const double*)ctx->coefs.ptr, B, C, k1_out, &handoff, d_uflag));
     F2_TRY(f2_launch_envelope(ctx, k1_out, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz,
-                              fft_precision, d_env, &handoff));
+                              fft_precision, d_env, &handoff, d_uflag));
     if (staged) {
         F2_HIP(ctx, hipMemcpyAsync(env, d_env, bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (gfb_or_null) F2_HIP(ctx, hipMemcpyAsync(gfb_or_null, d_gfb, bytes, hipMemcpyDeviceToHost, ctx->stream));

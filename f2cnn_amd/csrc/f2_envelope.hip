@@ -85,6 +85,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     const int u = blockIdx.x / P.C;
     const int c = blockIdx.x - u * P.C;
     const int b = P.ulist ? P.ulist[u] : u;
+    if (P.uflag && !P.uflag[b]) return;   // (whole workgroup) this utterance was served by the spectral kernel
     const int64_t off = P.offsets[b];
     const int n = (int)(P.offsets[b + 1] - off);
     const size_t row = (size_t)P.C * (size_t)off + (size_t)c * (size_t)n;
@@ -423,11 +424,13 @@ int f2_launch_envelope13_p3(f2_ctx* ctx, const f2_env_params& P, int precision, 
 }
 #else
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
-                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, const f2_handoff* handoff) {
+                       int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, const f2_handoff* handoff,
+                       const int* d_uflag) {
     const bool f32_in = handoff && handoff->f32;
     F2_CHECK(ctx, !f32_in || precision == F2_FFT_F32, F2_ERR_INVALID, "float32 hand-off needs the float FFT");
     EnvParams P;
     P.f32_in = f32_in ? 1 : 0;
+    P.uflag = d_uflag;
     P.stamps = nullptr;
 #ifdef F2_STAMPS
     static unsigned long long* d_stamps = nullptr;
@@ -448,7 +451,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
     // group the utterances by padded length (one kernel instantiation per FFT size)
     std::vector<std::vector<int>> groups(32), split_groups(32);
     std::vector<int> pair_group[2];   // [1]: 32769..65536 samples, two sub-rows per workgroup (f2_envelope_pair.hip)
-    const bool pair_ok = !getenv("F2CNN_NO_PAIR") && ((f32_in && handoff->d_x32) || (!f32_in && d_gfb != d_env));
+    const bool pair_ok = ctx->opt_env_pair && ((f32_in && handoff->d_x32) || (!f32_in && d_gfb != d_env));
     int n_large = 0;
     for (int b = 0; b < B; ++b) {
         const int64_t n = h_offsets[b + 1] - h_offsets[b];
@@ -519,7 +522,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
                              : (log2h == 13 && precision == F2_FFT_F32) ? F2_THREADS13 : log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
         const dim3 grid((unsigned)(g.size() * (size_t)C)), block(nthreads);
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
-        if (log2h == 13 && (!P.lpf || precision == F2_FFT_F64) && !getenv("F2CNN_PLAN4")) {
+        if (log2h == 13 && (!P.lpf || precision == F2_FFT_F64) && !ctx->opt_env_plan4) {
             // the 1 s row without the float low-pass: three-pass plan (f2_envelope_p3.hip)
             F2_TRY(f2_launch_envelope13_p3(ctx, P, precision, (unsigned)(g.size() * (size_t)C)));
         } else if (precision == F2_FFT_F32) {

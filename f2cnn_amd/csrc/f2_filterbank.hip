@@ -90,6 +90,8 @@ struct SplitArgs {
     const double* mtab;     // [C][8][8]: M = T^L, row major
     const int* order;       // MODE 3: units in the order they are handed out (longest first)
     int* queue;             // MODE 3: next position in `order` (zeroed before the launch)
+    const int* uflag;       // per utterance, or NULL: utterances whose flag is 0 are skipped (served by the spectral kernel)
+    int qwaves;             // MODE 3: waves of the launch (0 = from the batch)
 };
 
 // One unit of work = (utterance, group of 64 channels[, segment]) on one wave.
@@ -105,6 +107,7 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
     const int K = (MODE == 1 || MODE == 2) ? sp.K : 1;
     const int b = unit / groups;
     const int c0 = (unit % groups) * 64;
+    if (sp.uflag && !sp.uflag[b]) return;
     const int64_t off = offsets[b];
     const int64_t N = offsets[b + 1] - off;
     if (N <= 0) return;
@@ -386,8 +389,7 @@ void launch_fb(hipStream_t st, int units, bool a2zero, const void* wave, const i
         // units per wave at two per SIMD: with fewer, the second wave of a SIMD only takes the balancing away
         // (5000 utterances of 1-4 s in launches of 2500: 24.9 ms with 2048 waves against 28.8; launches of 1000: 27.1
         // against 28.1 the other way round)
-        const char* qw = getenv("F2CNN_K1_QWAVES");
-        const int waves = std::min(units, qw ? atoi(qw) : (units >= 4096 ? 2048 : 1024));
+        const int waves = std::max(1, std::min(units, sp.qwaves > 0 ? sp.qwaves : (units >= 4096 ? 2048 : 1024)));
         hipLaunchKernelGGL((k_erb_filterbank<WaveT, OutT, true, 3>), dim3((unsigned)((waves + WPB - 1) / WPB)), block, 0, st,
                            (const WaveT*)wave, offsets, coefs, C, groups, units, out, alt, alt_off, sp);
         return;
@@ -458,9 +460,7 @@ void transition_power(const double* coef_row, int L, double* M) {
 }
 
 // Segments per utterance for this batch: 1 (plain kernel) unless the batch is too small to fill the chip.
-int split_segments(int units, int64_t nmax, bool f32_out) {
-    const char* env = getenv("F2CNN_K1_SPLIT");            // 0 = never, K >= 2 = force K segments
-    const int forced = env ? atoi(env) : -1;
+int split_segments(int units, int64_t nmax, bool f32_out, int forced) {   // forced: -1 auto, 0 never, K >= 2 segments
     if (forced == 0 || nmax < 2 * SEG_ALIGN) return 1;
     // (measured, tools/k1_small_batch.py: with the float32 hand-off 192 units gain 1.7x, 384 units break even, 512 lose
     // 15 %; with float64 output, which is bound by its stores, 512 units lose 25 %)
@@ -473,7 +473,7 @@ int split_segments(int units, int64_t nmax, bool f32_out) {
 
 int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,
                          const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb,
-                         const f2_handoff* handoff) {
+                         const f2_handoff* handoff, const int* d_uflag) {
     const bool f32_out = handoff && handoff->f32;
     float* alt = f32_out ? handoff->d_x32 : nullptr;
     const int64_t* alt_off = f32_out ? handoff->d_x32_off : nullptr;
@@ -482,11 +482,11 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
     // the coefficient rows of this call are mirrored on the host by f2_upload_coefs
     bool a2zero = ctx->coefs_host.size() == (size_t)C * 10;
     for (int c = 0; a2zero && c < C; ++c) a2zero = ctx->coefs_host[(size_t)c * 10 + 5] == 0.0;
-    SplitArgs sp = {1, 0, nullptr, nullptr, nullptr, nullptr};
+    SplitArgs sp = {1, 0, nullptr, nullptr, nullptr, nullptr, d_uflag, ctx->opt_k1_qwaves};
     if (a2zero) {
         int64_t nmax = 0;
         for (int b = 0; b < B; ++b) nmax = std::max(nmax, h_offsets[b + 1] - h_offsets[b]);
-        const int K = split_segments(units, nmax, f32_out);
+        const int K = split_segments(units, nmax, f32_out, ctx->opt_k1_split);
         if (K > 1) {
             sp.L = (int)(((nmax + K - 1) / K + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN);
             sp.K = (int)((nmax + sp.L - 1) / sp.L);
@@ -509,8 +509,7 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
             // lengths that differ a lot: hand the units out longest first instead of one fixed unit per wave
             int64_t total = 0;
             for (int b = 0; b < B; ++b) total += h_offsets[b + 1] - h_offsets[b];
-            const char* env = getenv("F2CNN_K1_QUEUE");
-            const bool want = env ? atoi(env) != 0 : (units > 1024 && (double)nmax * B > 1.2 * (double)total);
+            const bool want = ctx->opt_k1_queue >= 0 ? ctx->opt_k1_queue != 0 : (units > 1024 && (double)nmax * B > 1.2 * (double)total);
             if (want) {
                 std::vector<int> order((size_t)units + 1);
                 std::vector<int> by_len((size_t)B);

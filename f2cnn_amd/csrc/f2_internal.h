@@ -17,6 +17,16 @@ struct f2_scratch {
     size_t bytes = 0;
 };
 
+// tables of the spectral filterbank + envelope kernel (f2_spectral.hip) for one (coefficient table, length class)
+struct f2_spec_tables {
+    int log2h = 0, C = 0;
+    std::vector<double> coefs;
+    int64_t tpitch = 0;
+    f2_scratch hu, e, lgroup;
+};
+#define F2_SPECTRAL_MIN_LOG2H 12   // rows of 4097 ... 16384 samples
+#define F2_SPECTRAL_MAX_LOG2H 13
+
 struct f2_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -53,6 +63,21 @@ struct f2_ctx {
     };
     std::vector<prof_span> prof[F2_K_COUNT];                         // one span per launch group
     std::vector<hipEvent_t> prof_pool;                               // recycled events
+    // spectral path (f2_spectral.hip)
+    std::vector<f2_spec_tables> spec_tabs;
+    f2_scratch spec_x, spec_rho;          // utterance spectra, per-row digits of the launch in flight
+    f2_scratch spec_meta, spec_uflag;     // [initial flags (B) | utterance lists]; the flags the kernels update
+    std::vector<int> spec_meta_host;      // what spec_meta currently holds
+    size_t spec_last_B = 0;               // batch size of the last fused call that used the spectral kernel (0: none)
+    f2_scratch tw_sp[2][16];              // its twiddle tables, [precision][log2 H]
+    // options (f2_ctx_set_option); -1 = decide from the batch
+    int opt_spectral = 1;                 // route eligible utterances of the fused call through the spectral kernel
+    float opt_spectral_tol = 4e-6f;       // accuracy guard: padding residual / row maximum that flags an utterance
+    int opt_k1_split = -1;                // segments of the time-split filterbank (0 = never, >= 2 = force)
+    int opt_k1_queue = -1;                // unit queue of the filterbank for ragged batches (0 / 1)
+    int opt_k1_qwaves = 0;                // waves of the queue launch (0 = from the batch)
+    int opt_env_pair = 1;                 // on-chip kernel for rows of 32769..65536 samples
+    int opt_env_plan4 = 0;                // four-pass plan for every 1 s row (default: three passes where measured faster)
     f2_scratch flags;      // small device words (error flags)
     int* host_flags = nullptr;  // pinned mirror
 };
@@ -105,6 +130,7 @@ struct f2_env_params {
     double* env;
     const int64_t* offsets;
     const int* ulist;  // utterances served by this launch (NULL: identity)
+    const int* uflag;  // per utterance of the batch, or NULL: rows of utterances whose flag is 0 are left alone
     int C;
     int lpf;
     int f32_in;        // input rows are float32 at the start of their float64 slot (hand-off from K1)
@@ -150,12 +176,20 @@ struct f2_handoff {
     const int64_t* h_x32_off = nullptr;     // the same on the host (owned by the context, valid until the next plan)
 };
 int f2_plan_handoff(f2_ctx* ctx, const int64_t* h_offsets, int B, int C, int precision, bool want_gfb, f2_handoff* plan);
+// d_uflag (device, B ints) != NULL: only utterances whose flag is non-zero are processed (the rest were served by the
+// spectral kernel); the flags may be written by earlier launches on the stream.
 int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,
                          const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb,
-                         const f2_handoff* handoff = nullptr);
+                         const f2_handoff* handoff = nullptr, const int* d_uflag = nullptr);
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
                        int B, int C, int lpf, double cutoff_hz, int precision, double* d_env,
-                       const f2_handoff* handoff = nullptr);
+                       const f2_handoff* handoff = nullptr, const int* d_uflag = nullptr);
+// Spectral filterbank + envelope (f2_spectral.hip): which utterances / coefficient tables it serves, and the launch for
+// the utterances d_ulist[0..nutt) (all of length class log2h). Rows that fail its accuracy guard set d_uflag[b].
+bool f2_spectral_supports_len(int64_t n);
+bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::vector<int>* Lgroup);
+int f2_launch_spectral(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets, const double* d_coefs,
+                       int C, const int* d_ulist, int nutt, int log2h, int lpf, double cutoff_hz, double* d_env, int* d_uflag);
 // d_centers == NULL: window e is centred at first_center + e
 int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const int64_t* d_centers,
                      int64_t first_center, int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag);

@@ -1,0 +1,621 @@
+// KS -- filterbank + Hilbert envelope (+ low-pass) of a row WITHOUT the time-domain filterbank output: the spectrum of
+// the zero-padded channel signal is formed directly from the spectrum of the utterance, so the (C, n) filterbank matrix
+// never exists - neither in HBM nor on chip. Same results as K1 -> K2 (reference: gammatone/filters.py:195-239
+// erb_filterbank followed by scripts/processing/EnvelopeExtraction.py:20-67) within the float32-FFT tolerance.
+//
+// Mathematics (prototype with the derivation checked against the oracle: tools/proto_spectral.py).  Row = channel c of
+// an utterance of n samples, M = 2^ceil(log2 n), H = M/2, z_k = exp(2 pi i k / M), w = 1/z_k.  The cascade of the four
+// second-order sections  D(w) y_m = N_m(w) y_(m-1),  D = 1 + a1 w + a2 w^2,  N_m = 1 + c_m w  (make_erb_filters: shared
+// poles, no w^2 term in the numerators; overall factor s = (A0/B0)^4 / gain) holds for the samples n' < n; for the
+// sequences cut at n it leaves a residue at n, n+1:   D Y_m = N_m Y_(m-1) + w^n R_m(w),  deg R_m <= 1, a linear function
+// of the section's two state words at sample n.  Hence, with u = 1/D(w_k) and X = DFT_M(x zero-padded),
+//
+//     Y(k) = s [ u^4 N_1 N_2 N_3 N_4 X(k)  +  w^n u^4 Q(w) ],   Q = R_4 D^3 + N_4 R_3 D^2 + N_4 N_3 R_2 D + N_4 N_3 N_2 R_1
+//
+// is the DFT of the zero-padded filterbank row: the first term is the M-periodic steady response, the second removes
+// the ringing after sample n (which a circular product alone would wrap around). Q is evaluated through its D-adic
+// digits  Q = r_0 + r_1 D + r_2 D^2 + r_3 D^3  (deg r_j <= 1):  u^4 Q = u (r_3 + u (r_2 + u (r_1 + u r_0))), a Horner
+// chain without cancellation (the monomial form of Q loses 1/|D|^3 ~ 1e9 near the resonance of the low channels).
+// The state words at sample n only depend on the last L samples of the utterance (poles of radius r: n^3 r^n < 1e-10
+// of its peak beyond L; L = 150 ... 2400 samples for the 128-channel bank): k_tail_state runs the float64 recurrences
+// of K1 over those samples only and leaves the eight digit coefficients of every row.
+//
+// The analytic signal a = IDFT_M of the one-sided spectrum A (A(k) = 2 Y(k), 0 < k < H; Y(0); Y(H)) is computed for the
+// even and the odd samples by two H-point complex transforms,  a[2m] = IDFT_H(A_e)[m], A_e(k) = A(k) (k = 0: A(0) + A(H)),
+// a[2m+1] = IDFT_H(A_o)[m], A_o(k) = A(k) z_k (k = 0: A(0) - A(H)) - the same two transforms per row as K2 runs (there:
+// forward of the packed row, inverse of the packed Hilbert spectrum), both register -> register here.  Envelope =
+// |a|, then the low-pass in the register layout the transforms leave (f2_envelope_core.h), float64 rows out.
+//
+// Accuracy guard: the two terms of Y are rounded in float32 separately, each ~6e-8 of the LARGER of (steady response,
+// ringing). A row whose ringing after sample n dwarfs everything inside [0, n) (an isolated click in the last
+// milliseconds) would therefore lose accuracy relative to its own maximum. Every workgroup computes all M samples
+// anyway: the real part of a over the padding region [n, M) - the zero-padded row itself, zero in exact arithmetic
+// (the imaginary part is not: a Hilbert transform is not time-limited) - measures the error directly;
+// if its maximum exceeds `tol` x the row's maximum the utterance is flagged and the caller's K1 -> K2 launches (which skip
+// unflagged utterances) recompute it. Utterances with fewer than 64 padding samples are never routed here.
+//
+// Traffic: 8 bytes written per sample-channel (the ENV1 rows); tables (1 MB per XCD for 128 channels), utterance
+// spectra (64 KB per utterance, shared by its C rows) and 32 bytes of digits per row come from L2. Bound: f32 VALU +
+// LDS exchanges.
+#define f2fft f2fft_sp   // own copy of the FFT templates (the radix plan of this kernel is chosen independently of K2's)
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <thread>
+
+#include "f2_fft_lds.h"
+
+using namespace f2fft;
+
+namespace {
+
+typedef float f2_f4 __attribute__((ext_vector_type(4)));
+
+struct SpecParams {
+    const cpx<float>* X;      // [nutt][xpitch] spectra of the utterances of this launch, k = 0..H
+    int64_t xpitch;
+    const f2_f4* HU;          // [C][tpitch] {Hs.re, Hs.im, u.re, u.im}, Hs = (2/M) s N_1..N_4 u^4
+    int64_t tpitch;
+    const cpx<float>* E;      // [M] exp(-2 pi i q / M)
+    const float* rho;         // [nutt * C][8] digits r_0..r_3 of Q, scaled by (2/M) s
+    double* env;
+    const int64_t* offsets;
+    const int* ulist;         // utterances of this launch (device)
+    int* uflag;               // [B] set to 1 when a row of the utterance fails the accuracy guard
+    int C;
+    int lpf;
+    double b0, a1;
+    float tol;
+};
+
+// Y'(k) = (2/M) Y(k) of one bin
+__device__ __forceinline__ cpx<float> spectral_bin(cpx<float> X, f2_f4 hu, cpx<float> w, cpx<float> z, const float* __restrict__ rho) {
+    const float ur = hu.z, ui = hu.w;
+    float tr = fmaf(rho[1], w.re, rho[0]), ti = rho[1] * w.im;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        const float rr = fmaf(rho[2 * j + 1], w.re, rho[2 * j]), ri = rho[2 * j + 1] * w.im;
+        const float nr = fmaf(-ui, ti, fmaf(ur, tr, rr));
+        const float ni = fmaf(ui, tr, fmaf(ur, ti, ri));
+        tr = nr;
+        ti = ni;
+    }
+    const float qr = ur * tr - ui * ti, qi = ur * ti + ui * tr;
+    float yr = hu.x * X.re;
+    yr = fmaf(-hu.y, X.im, yr);
+    yr = fmaf(z.re, qr, yr);
+    yr = fmaf(-z.im, qi, yr);
+    float yi = hu.x * X.im;
+    yi = fmaf(hu.y, X.re, yi);
+    yi = fmaf(z.re, qi, yi);
+    yi = fmaf(z.im, qr, yi);
+    return {yr, yi};
+}
+
+// maximum over the wave, result valid in lane 63 (row_shr 1/2/4/8, row_bcast 15/31; values >= 0, missing lanes read 0)
+__device__ __forceinline__ float wave_max63(float v) {
+    v = fmaxf(v, dpp_mov<0x111, 0xF>(v));
+    v = fmaxf(v, dpp_mov<0x112, 0xF>(v));
+    v = fmaxf(v, dpp_mov<0x114, 0xF>(v));
+    v = fmaxf(v, dpp_mov<0x118, 0xF>(v));
+    v = fmaxf(v, dpp_mov<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_mov<0x143, 0xC>(v));
+    return v;
+}
+
+template <int LOG2H>
+__global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float, LOG2H>())) void k_spectral_envelope(
+    SpecParams P, const cpx<float>* __restrict__ tw) {
+    constexpr int NT = threads_for<float, LOG2H>();
+    constexpr int H = 1 << LOG2H;
+    constexpr int M = 2 * H;
+    constexpr int CS = cpad_size(H);
+    constexpr int R0 = 1 << plan_bits(LOG2H, 0);
+    constexpr int NB0 = H / R0;
+    static_assert(NB0 % NT == 0, "every thread owns whole butterflies of the first pass");
+    constexpr int ITER0 = NB0 / NT;
+    constexpr int PT = plan_points_per_thread(LOG2H, NT);
+    constexpr int NBLK = ITER0 * R0;
+    static_assert(PT == NBLK, "register shape");
+    constexpr size_t LP = lowpass_lds_bytes<float, NT, NBLK>();
+    constexpr int LDS_BYTES = (int)((size_t)CS * 8 > LP ? (size_t)CS * 8 : LP);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    constexpr int TWL = plan_tw_lds_count(LOG2H);
+    __shared__ __attribute__((aligned(16))) cpx<float> twl[TWL > 0 ? TWL : 1];
+    __shared__ unsigned guard[2];   // max |a| inside [0, n) / inside [n, M), as float bits (values >= 0)
+    cpx<float>* lds = reinterpret_cast<cpx<float>*>(smem);
+
+    const int tid = threadIdx.x;
+    const int u = blockIdx.x / P.C;
+    const int c = blockIdx.x - u * P.C;
+    const int b = P.ulist[u];
+    const int64_t off = P.offsets[b];
+    const int n = (int)(P.offsets[b + 1] - off);
+    double* __restrict__ y = P.env + ((size_t)P.C * (size_t)off + (size_t)c * (size_t)n);
+    const float* __restrict__ rho = P.rho + (size_t)blockIdx.x * 8;
+    const cpx<float>* __restrict__ Xu = P.X + (size_t)u * P.xpitch;
+    const f2_f4* __restrict__ HUc = P.HU + (size_t)c * P.tpitch;
+    const cpx<float>* __restrict__ E = P.E;
+
+    for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2H, 1) + i];
+    if (tid < 2) guard[tid] = 0u;
+
+    // 1. spectrum of the zero-padded row at this thread's bins k = tid + i NT + j NB0 (first-pass register layout)
+    cpx<float> yk[PT], v[PT];
+    const unsigned zstep = ((unsigned)NB0 * (unsigned)n) & (M - 1);
+#pragma unroll
+    for (int i = 0; i < ITER0; ++i) {
+        const int bf = tid + i * NT;
+        unsigned zi = __umul24((unsigned)bf, (unsigned)n) & (M - 1);   // (k n) mod M, k = bf + j NB0
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+            const int k = bf + j * NB0;
+            yk[i * R0 + j] = spectral_bin(Xu[k], HUc[k], E[k], E[zi], rho);
+            zi = (zi + zstep) & (M - 1);
+        }
+    }
+    // k = 0 carries the Nyquist term: A_e(0) = A(0) + A(H), A_o(0) = A(0) - A(H) (both real); thread 0 keeps
+    // (Y'(0), Y'(H)) in yk[0]
+    if (tid == 0) {
+        const cpx<float> yh = spectral_bin(Xu[H], HUc[H], cpx<float>{-1.f, 0.f}, cpx<float>{(n & 1) ? -1.f : 1.f, 0.f}, rho);
+        yk[0] = {yk[0].re, yh.re};
+    }
+    // 2. even samples: conj(a[2m]) = DFT_H(conj(A_e) / M)
+#pragma unroll
+    for (int q = 0; q < PT; ++q) v[q] = {yk[q].re, -yk[q].im};
+    if (tid == 0) v[0] = {0.5f * (yk[0].re + yk[0].im), 0.f};
+    constexpr bool T0R = derive_tw0<float, LOG2H>();
+    fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid, v);
+    // the last pass left sample m = bf + j NB0 in v[i R0 + brev(j)]
+    float er[NBLK], ei[NBLK];
+#pragma unroll
+    for (int i = 0; i < ITER0; ++i)
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+            const cpx<float> a = v[i * R0 + brev<R0>(j)];
+            er[i + ITER0 * j] = fsqrt(a.re * a.re + a.im * a.im);
+        }
+    const float pad_e = fabsf(v[(ITER0 - 1) * R0 + brev<R0>(R0 - 1)].re);   // |Re a| of the last block's even sample
+    // 3. odd samples: conj(a[2m+1]) = DFT_H(conj(A_o) / M), conj(A_o(k)) = conj(A(k)) w_k
+#pragma unroll
+    for (int i = 0; i < ITER0; ++i) {
+        const int bf = tid + i * NT;
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+            const cpx<float> w = E[bf + j * NB0];
+            const cpx<float> a = yk[i * R0 + j];
+            v[i * R0 + j] = {a.re * w.re + a.im * w.im, a.re * w.im - a.im * w.re};
+        }
+    }
+    if (tid == 0) v[0] = {0.5f * (yk[0].re - yk[0].im), 0.f};
+    fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid, v);
+#pragma unroll
+    for (int i = 0; i < ITER0; ++i)
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+            const cpx<float> a = v[i * R0 + brev<R0>(j)];
+            ei[i + ITER0 * j] = fsqrt(a.re * a.re + a.im * a.im);
+        }
+    const float pad_o = fabsf(v[(ITER0 - 1) * R0 + brev<R0>(R0 - 1)].re);
+    // 4. accuracy guard: block jj of this thread is the sample pair 2 (tid + NT jj), + 1. Inside [0, n) the row's
+    //    maximum; in the padding region the REAL part of a (the zero-padded row itself: zero in exact arithmetic, while
+    //    the imaginary part, the Hilbert transform of a time-limited signal, is not) - sampled in the last block, which
+    //    holds at least 64 padding samples of every row routed here.
+    float gin = 0.f, gout = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < NBLK; ++jj) {
+        const int lo = 2 * NT * jj;
+        if (lo + 2 * NT <= n) {
+            gin = fmaxf(gin, fmaxf(er[jj], ei[jj]));
+        } else if (lo < n) {
+            const int i0 = lo + 2 * tid;
+            gin = fmaxf(gin, fmaxf(i0 < n ? er[jj] : 0.f, i0 + 1 < n ? ei[jj] : 0.f));
+        }
+    }
+    {
+        const int i0 = 2 * (tid + NT * (NBLK - 1));
+        gout = fmaxf(i0 >= n ? pad_e : 0.f, i0 + 1 >= n ? pad_o : 0.f);
+    }
+    gin = wave_max63(gin);
+    gout = wave_max63(gout);
+    if ((tid & 63) == 63) {
+        atomicMax(&guard[0], __float_as_uint(gin));
+        atomicMax(&guard[1], __float_as_uint(gout));
+    }
+    // 5. stores (the last pass of the transform ended with a barrier after its LDS reads: smem is free)
+    if (!P.lpf) {
+#pragma unroll
+        for (int jj = 0; jj < NBLK; ++jj) store_row_pair(y, n, 2 * (tid + NT * jj), (double)er[jj], (double)ei[jj]);
+        __syncthreads();
+    } else {
+        lowpass_pairs_store<float, NT, NBLK>(er, ei, P.a1, P.b0, smem, y, n, tid);   // (contains barriers)
+    }
+    if (tid == 0) {
+        const float gi = __uint_as_float(guard[0]), go = __uint_as_float(guard[1]);
+        if (go > P.tol * gi) P.uflag[b] = 1;
+    }
+}
+
+// ---- X = DFT_M(x zero-padded), k = 0..H, float64 arithmetic, float32 out: one workgroup per utterance ----
+// (float64: the float32 rounding of a transform is relative to the LOUDEST band of the utterance; a channel that sits
+// 60 dB below it - speech above 4 kHz - would inherit 1e-4 of its own level.)
+template <typename WaveT, int LOG2H>
+__global__ __launch_bounds__((threads_for<double, LOG2H>())) void k_utterance_spectrum(const WaveT* __restrict__ wave,
+                                                                                     const int64_t* __restrict__ offsets,
+                                                                                     const int* __restrict__ ulist,
+                                                                                     cpx<float>* __restrict__ X, int64_t xpitch,
+                                                                                     const cpx<double>* __restrict__ tw) {
+    constexpr int NT = threads_for<double, LOG2H>();
+    constexpr int H = 1 << LOG2H;
+    constexpr int CS = cpad_size(H);
+    constexpr int R0 = 1 << plan_bits(LOG2H, 0);
+    constexpr int NB0 = H / R0;
+    constexpr int ITER0 = (NB0 + NT - 1) / NT;
+    constexpr int PT = plan_points_per_thread(LOG2H, NT);
+    constexpr bool FULL0 = NB0 % NT == 0;
+    __shared__ __attribute__((aligned(16))) cpx<double> lds[CS];
+    constexpr int TWL = plan_tw_lds_count(LOG2H);
+    __shared__ __attribute__((aligned(16))) cpx<double> twl[TWL > 0 ? TWL : 1];
+    const cpx<double>* __restrict__ V = tw + plan_tw_total(LOG2H);   // exp(-2 pi i k / M), k <= H/2
+    const int tid = threadIdx.x;
+    const int b = ulist[blockIdx.x];
+    const int64_t off = offsets[b];
+    const int n = (int)(offsets[b + 1] - off);
+    const WaveT* __restrict__ x = wave + off;
+    cpx<float>* __restrict__ Xo = X + (size_t)blockIdx.x * xpitch;
+    for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2H, 1) + i];
+    cpx<double> v[PT];
+#pragma unroll
+    for (int i = 0; i < ITER0; ++i) {
+        const int bf = tid + i * NT;
+        if (FULL0 || bf < NB0) {
+#pragma unroll
+            for (int j = 0; j < R0; ++j) {
+                const int i0 = 2 * (bf + j * NB0);
+                v[i * R0 + j] = {i0 < n ? (double)x[i0] : 0.0, i0 + 1 < n ? (double)x[i0 + 1] : 0.0};
+            }
+        }
+    }
+    fft_all<double, LOG2H, false, PT, NT, false>(lds, tw, twl, tid, v);   // Z = FFT_H(x[2m] + i x[2m+1]) in lds[cpad(k)]
+    // X(k) = E(k) + w_k O(k), E = (Z(k) + conj Z(H-k)) / 2, O = (Z(k) - conj Z(H-k)) / (2i); X(H-k) = conj(E - w_k O)
+    for (int k = 1 + tid; k <= H / 2; k += NT) {
+        const cpx<double> zk = lds[cpad(k)], zh = lds[cpad(H - k)];
+        const cpx<double> e = {0.5 * (zk.re + zh.re), 0.5 * (zk.im - zh.im)};
+        const cpx<double> o = {0.5 * (zk.im + zh.im), -0.5 * (zk.re - zh.re)};
+        const cpx<double> w = V[k];
+        const cpx<double> wo = {o.re * w.re - o.im * w.im, o.re * w.im + o.im * w.re};
+        Xo[k] = {(float)(e.re + wo.re), (float)(e.im + wo.im)};
+        Xo[H - k] = {(float)(e.re - wo.re), (float)(-(e.im - wo.im))};
+    }
+    if (tid == 0) {
+        const cpx<double> z0 = lds[cpad(0)];
+        Xo[0] = {(float)(z0.re + z0.im), 0.f};
+        Xo[H] = {(float)(z0.re - z0.im), 0.f};
+    }
+}
+
+// ---- state of the cascade at the end of every row -> digits of Q (float64), one wave = 64 channels of an utterance ----
+constexpr int TAIL_TB = 32;
+constexpr int TAIL_WAVES = 4;
+
+template <typename WaveT>
+__global__ __launch_bounds__((64 * TAIL_WAVES)) void k_tail_state(const WaveT* __restrict__ wave, const int64_t* __restrict__ offsets,
+                                                                const double* __restrict__ coefs, int C, int groups,
+                                                                const int* __restrict__ ulist, int nutt,
+                                                                const int* __restrict__ Lgroup, float* __restrict__ rho,
+                                                                double two_over_m) {
+    __shared__ double xss[TAIL_WAVES][TAIL_TB];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * TAIL_WAVES + wid;
+    if (unit >= nutt * groups) return;   // whole wave; the waves of a workgroup never meet at a barrier
+    const int ul = unit / groups, g = unit - ul * groups;
+    const int b = ulist[ul];
+    const int64_t off = offsets[b];
+    const int64_t N = offsets[b + 1] - off;
+    const int cc = g * 64 + lane;
+    const int c = min(cc, C - 1);
+    const double* k = coefs + (size_t)c * 10;
+    const double rB0 = 1.0 / k[6];
+    const double b0 = k[0] * rB0, a1 = k[7] * rB0, a2 = k[8] * rB0;
+    const double c1 = k[1] / k[0], c2 = k[2] / k[0], c3 = k[3] / k[0], c4 = k[4] / k[0];
+    const double scale = (b0 * b0) * (b0 * b0) / k[9] * two_over_m;
+    double* xs = xss[wid];
+    const WaveT* w = wave + off;
+    // the recurrences start from zero state TB * nblk samples before the end (samples before the utterance are zero)
+    const int64_t L = min((int64_t)Lgroup[g], N);
+    const int64_t nblk = (L + TAIL_TB - 1) / TAIL_TB;
+    const int64_t t_begin = N - nblk * TAIL_TB;
+    double z10 = 0, z11 = 0, z20 = 0, z21 = 0, z30 = 0, z31 = 0, z40 = 0, z41 = 0;
+    auto sample = [&](int64_t t) { return (lane < TAIL_TB && t >= 0 && t < N) ? (double)w[t] : 0.0; };
+    double xnext = sample(t_begin + lane);
+    for (int64_t t0 = t_begin; t0 < N; t0 += TAIL_TB) {
+        if (lane < TAIL_TB) xs[lane] = xnext;
+        xnext = sample(t0 + TAIL_TB + lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the four sections skewed by one sample each (as K1): four independent float64 chains per step
+        double p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < TAIL_TB + 3; ++s2) {
+            double n1 = 0, n2 = 0, n3 = 0;
+            if (s2 < TAIL_TB) {
+                const double wv = fma(-a1, z10, fma(-a2, z11, xs[s2]));
+                n1 = fma(c1, z10, wv);
+                z11 = z10;
+                z10 = wv;
+            }
+            if (s2 >= 1 && s2 - 1 < TAIL_TB) {
+                const double wv = fma(-a1, z20, fma(-a2, z21, p1));
+                n2 = fma(c2, z20, wv);
+                z21 = z20;
+                z20 = wv;
+            }
+            if (s2 >= 2 && s2 - 2 < TAIL_TB) {
+                const double wv = fma(-a1, z30, fma(-a2, z31, p2));
+                n3 = fma(c3, z30, wv);
+                z31 = z30;
+                z30 = wv;
+            }
+            if (s2 >= 3) {
+                const double wv = fma(-a1, z40, fma(-a2, z41, p3));
+                z41 = z40;
+                z40 = wv;
+            }
+            p1 = n1;
+            p2 = n2;
+            p3 = n3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // residues R_m = (R_m0, R_m1) of the sections from their state words (w_m[n-1], w_m[n-2])
+    const double ia2 = 1.0 / a2;
+    const double R10 = (a1 - c1) * z10 + a2 * z11, R11 = a2 * z10 + c1 * a2 * z11;
+    const double R20 = (a1 - c2) * z20 + a2 * z21, R21 = a2 * z20 + c2 * a2 * z21;
+    const double R30 = (a1 - c3) * z30 + a2 * z31, R31 = a2 * z30 + c3 * a2 * z31;
+    const double R40 = (a1 - c4) * z40 + a2 * z41, R41 = a2 * z40 + c4 * a2 * z41;
+    double d0[2], d1[2], d2[2], d3[2];
+    // R_4 D^3
+    d3[0] = R40;
+    d3[1] = R41;
+    {   // N_4 R_3 D^2: degree 2 = q D + rem
+        const double p0 = R30, p1q = R31 + c4 * R30, p2q = c4 * R31;
+        const double q = p2q * ia2;
+        d2[0] = p0 - q;
+        d2[1] = p1q - q * a1;
+        d3[0] += q;
+    }
+    {   // N_4 N_3 R_2 D: degree 3 = (q0 + q1 w) D + rem
+        const double s0 = 1.0, s1 = c4 + c3, s2 = c4 * c3;   // N_4 N_3
+        double p0 = s0 * R20, p1q = s0 * R21 + s1 * R20, p2q = s1 * R21 + s2 * R20, p3q = s2 * R21;
+        const double q1 = p3q * ia2;
+        p2q -= q1 * a1;
+        p1q -= q1;
+        const double q0 = p2q * ia2;
+        p1q -= q0 * a1;
+        p0 -= q0;
+        d1[0] = p0;
+        d1[1] = p1q;
+        d2[0] += q0;
+        d2[1] += q1;
+    }
+    {   // N_4 N_3 N_2 R_1: degree 4 = (q0 + q1 w + q2 w^2) D + rem; the quotient once more = qq D + rem'
+        const double s0 = 1.0, s1 = c4 + c3, s2 = c4 * c3;
+        const double t0 = s0, t1 = s1 + c2 * s0, t2 = s2 + c2 * s1, t3 = c2 * s2;   // N_4 N_3 N_2
+        double p0 = t0 * R10, p1q = t0 * R11 + t1 * R10, p2q = t1 * R11 + t2 * R10, p3q = t2 * R11 + t3 * R10, p4q = t3 * R11;
+        const double q2 = p4q * ia2;
+        p3q -= q2 * a1;
+        p2q -= q2;
+        const double q1 = p3q * ia2;
+        p2q -= q1 * a1;
+        p1q -= q1;
+        const double q0 = p2q * ia2;
+        p1q -= q0 * a1;
+        p0 -= q0;
+        d0[0] = p0;
+        d0[1] = p1q;
+        const double qq = q2 * ia2;
+        d1[0] += q0 - qq;
+        d1[1] += q1 - qq * a1;
+        d2[0] += qq;
+    }
+    if (cc < C) {
+        float* r = rho + ((size_t)ul * C + cc) * 8;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<f4*>(r) = f4{(float)(d0[0] * scale), (float)(d0[1] * scale), (float)(d1[0] * scale), (float)(d1[1] * scale)};
+        *reinterpret_cast<f4*>(r + 4) = f4{(float)(d2[0] * scale), (float)(d2[1] * scale), (float)(d3[0] * scale), (float)(d3[1] * scale)};
+    }
+}
+
+// samples after which n^3 r^n stays below tol x its peak (r = pole radius); 0 if the poles are not a complex pair
+// inside the unit circle or the answer exceeds `limit`
+int64_t ringing_length(double a1, double a2, double tol, int64_t limit) {
+    if (!(a2 > 1e-3 && a2 < 1.0) || a1 * a1 >= 4.0 * a2) return 0;
+    const double lr = 0.5 * std::log(a2);   // log r < 0
+    const double np = std::max(1.0, -3.0 / lr);
+    const double target = std::log(tol) + 3.0 * std::log(np) + np * lr;   // log(tol * peak)
+    double lo = np, hi = np;
+    while (3.0 * std::log(hi) + hi * lr > target) {
+        hi *= 2;
+        if (hi > (double)limit) return 0;
+    }
+    for (int it = 0; it < 60; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (3.0 * std::log(mid) + mid * lr > target) lo = mid;
+        else hi = mid;
+    }
+    return (int64_t)std::ceil(hi) + 64;
+}
+
+}  // namespace
+
+// ---- host: eligibility, tables, launch ----
+bool f2_spectral_supports_len(int64_t n) {
+    if (n < 2) return false;
+    const int log2h = f2_log2_ceil(n) - 1;
+    if (log2h < F2_SPECTRAL_MIN_LOG2H || log2h > F2_SPECTRAL_MAX_LOG2H) return false;
+    return (int64_t(2) << log2h) - n >= 64;   // the accuracy guard needs padding samples to look at
+}
+
+bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::vector<int>* Lgroup) {
+    if (coefs.size() != (size_t)C * 10 || C <= 0) return false;
+    const int groups = (C + 63) / 64;
+    if (Lgroup) Lgroup->assign((size_t)groups, 0);
+    for (int c = 0; c < C; ++c) {
+        const double* k = &coefs[(size_t)c * 10];
+        if (k[5] != 0.0 || k[0] == 0.0 || k[6] == 0.0 || k[9] == 0.0) return false;
+        for (int q = 0; q < 10; ++q)
+            if (!std::isfinite(k[q])) return false;
+        const int64_t L = ringing_length(k[7] / k[6], k[8] / k[6], 1e-10, int64_t(1) << 17);
+        if (L <= 0) return false;
+        if (Lgroup) (*Lgroup)[(size_t)c / 64] = std::max((*Lgroup)[(size_t)c / 64], (int)L);
+    }
+    return true;
+}
+
+static int spectral_tables(f2_ctx* ctx, int C, int log2h, f2_spec_tables** out) {
+    for (auto& t : ctx->spec_tabs)
+        if (t.log2h == log2h && t.C == C && t.coefs == ctx->coefs_host) {
+            *out = &t;
+            return F2_OK;
+        }
+    if (ctx->spec_tabs.size() >= 6) {   // a handful of (table, length class) pairs at most; drop the oldest
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (f2_scratch* s : {&ctx->spec_tabs.front().hu, &ctx->spec_tabs.front().e, &ctx->spec_tabs.front().lgroup})
+            if (s->ptr) (void)hipFree(s->ptr);
+        ctx->spec_tabs.erase(ctx->spec_tabs.begin());
+    }
+    f2_spec_tables t;
+    t.log2h = log2h;
+    t.C = C;
+    t.coefs = ctx->coefs_host;
+    std::vector<int> Lg;
+    if (!f2_spectral_supports_coefs(t.coefs, C, &Lg)) return f2_fail(ctx, F2_ERR_INVALID, "coefficient table not eligible");
+    const int H = 1 << log2h, M = 2 * H;
+    t.tpitch = H + 8;
+    typedef std::complex<double> cd;
+    std::vector<cd> w((size_t)M);
+    std::vector<float> e((size_t)M * 2);
+    const long double tau = 2.0L * 3.14159265358979323846264338327950288L;
+    for (int q = 0; q < M; ++q) {
+        const long double ang = tau * (long double)q / (long double)M;
+        w[(size_t)q] = cd((double)cosl(ang), (double)(-sinl(ang)));
+        e[2 * (size_t)q] = (float)cosl(ang);
+        e[2 * (size_t)q + 1] = (float)(-sinl(ang));
+    }
+    std::vector<float> hu((size_t)C * t.tpitch * 4, 0.f);
+    auto work = [&](int cbeg, int cend) {
+        for (int c = cbeg; c < cend; ++c) {
+            const double* k = &t.coefs[(size_t)c * 10];
+            const double rB0 = 1.0 / k[6];
+            const double b0 = k[0] * rB0, a1 = k[7] * rB0, a2 = k[8] * rB0;
+            const double cm[4] = {k[1] / k[0], k[2] / k[0], k[3] / k[0], k[4] / k[0]};
+            const double s = (b0 * b0) * (b0 * b0) / k[9] * (2.0 / M);
+            float* row = &hu[(size_t)c * t.tpitch * 4];
+            for (int q = 0; q <= H; ++q) {
+                const cd wq = w[(size_t)q];
+                const cd u = 1.0 / (1.0 + a1 * wq + a2 * wq * wq);
+                cd h = s;
+                for (int m = 0; m < 4; ++m) h *= (1.0 + cm[m] * wq) * u;
+                row[4 * (size_t)q] = (float)h.real();
+                row[4 * (size_t)q + 1] = (float)h.imag();
+                row[4 * (size_t)q + 2] = (float)u.real();
+                row[4 * (size_t)q + 3] = (float)u.imag();
+            }
+        }
+    };
+    {
+        const int nth = std::max(1, std::min(8, C / 8));
+        std::vector<std::thread> th;
+        for (int i = 0; i < nth; ++i) th.emplace_back(work, C * i / nth, C * (i + 1) / nth);
+        for (auto& x : th) x.join();
+    }
+    F2_TRY(f2_reserve(ctx, t.hu, sizeof(float) * hu.size()));
+    F2_TRY(f2_reserve(ctx, t.e, sizeof(float) * e.size()));
+    F2_TRY(f2_reserve(ctx, t.lgroup, sizeof(int) * Lg.size()));
+    F2_HIP(ctx, hipMemcpyAsync(t.hu.ptr, hu.data(), sizeof(float) * hu.size(), hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipMemcpyAsync(t.e.ptr, e.data(), sizeof(float) * e.size(), hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipMemcpyAsync(t.lgroup.ptr, Lg.data(), sizeof(int) * Lg.size(), hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the sources are locals (one-time table build)
+    ctx->spec_tabs.push_back(std::move(t));
+    *out = &ctx->spec_tabs.back();
+    return F2_OK;
+}
+
+template <typename WaveT, int LOG2H>
+static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offsets, const double* d_coefs, int C,
+                        const int* d_ulist, int nutt, int lpf, double b0, double a1, double* d_env, int* d_uflag, float tol,
+                        cpx<float>* d_X, float* d_rho) {
+    constexpr int H = 1 << LOG2H, M = 2 * H;
+    f2_spec_tables* tab = nullptr;
+    F2_TRY(spectral_tables(ctx, C, LOG2H, &tab));
+    F2_TRY(ensure_twiddles<double>(ctx, LOG2H, ctx->tw_sp[1][LOG2H]));
+    F2_TRY(ensure_twiddles<float>(ctx, LOG2H, ctx->tw_sp[0][LOG2H]));
+    const int64_t xpitch = H + 8;
+    const int groups = (C + 63) / 64;
+    F2_TRY(f2_prof_begin(ctx, F2_K_SPECTRUM));
+    hipLaunchKernelGGL((k_utterance_spectrum<WaveT, LOG2H>), dim3((unsigned)nutt), dim3(threads_for<double, LOG2H>()), 0, ctx->stream,
+                       d_wave, d_offsets, d_ulist, d_X, xpitch, (const cpx<double>*)ctx->tw_sp[1][LOG2H].ptr);
+    F2_HIP(ctx, hipGetLastError());
+    F2_TRY(f2_prof_end(ctx, F2_K_SPECTRUM));
+    F2_TRY(f2_prof_begin(ctx, F2_K_TAIL));
+    const int units = nutt * groups;
+    hipLaunchKernelGGL((k_tail_state<WaveT>), dim3((unsigned)((units + TAIL_WAVES - 1) / TAIL_WAVES)), dim3(64 * TAIL_WAVES), 0,
+                       ctx->stream, d_wave, d_offsets, d_coefs, C, groups, d_ulist, nutt, (const int*)tab->lgroup.ptr, d_rho,
+                       2.0 / M);
+    F2_HIP(ctx, hipGetLastError());
+    F2_TRY(f2_prof_end(ctx, F2_K_TAIL));
+    SpecParams P;
+    P.X = d_X;
+    P.xpitch = xpitch;
+    P.HU = (const f2_f4*)tab->hu.ptr;
+    P.tpitch = tab->tpitch;
+    P.E = (const cpx<float>*)tab->e.ptr;
+    P.rho = d_rho;
+    P.env = d_env;
+    P.offsets = d_offsets;
+    P.ulist = d_ulist;
+    P.uflag = d_uflag;
+    P.C = C;
+    P.lpf = lpf;
+    P.b0 = b0;
+    P.a1 = a1;
+    P.tol = tol;
+    F2_TRY(f2_prof_begin(ctx, F2_K_FUSED));
+    hipLaunchKernelGGL((k_spectral_envelope<LOG2H>), dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, LOG2H>()), 0,
+                       ctx->stream, P, (const cpx<float>*)ctx->tw_sp[0][LOG2H].ptr);
+    F2_HIP(ctx, hipGetLastError());
+    F2_TRY(f2_prof_end(ctx, F2_K_FUSED));
+    return F2_OK;
+}
+
+// Envelopes of the utterances `utts` (host list, all of length class log2h and eligible) straight from the waves.
+int f2_launch_spectral(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets, const double* d_coefs,
+                       int C, const int* d_ulist, int nutt, int log2h, int lpf, double cutoff_hz, double* d_env, int* d_uflag) {
+    if (nutt <= 0) return F2_OK;
+    const double k = lpf ? tan(3.14159265358979323846 * cutoff_hz / 16000.0) : 0.0;
+    const double b0 = k / (1.0 + k), a1 = (k - 1.0) / (k + 1.0);
+    const float tol = ctx->opt_spectral_tol;
+    const int H = 1 << log2h;
+    F2_TRY(f2_reserve(ctx, ctx->spec_x, sizeof(float) * 2 * (size_t)(H + 8) * (size_t)nutt));
+    F2_TRY(f2_reserve(ctx, ctx->spec_rho, sizeof(float) * 8 * (size_t)nutt * (size_t)C));
+    cpx<float>* d_X = (cpx<float>*)ctx->spec_x.ptr;
+    float* d_rho = (float*)ctx->spec_rho.ptr;
+#define F2_SPEC_CASE(L)                                                                                                          \
+    case L:                                                                                                                      \
+        return wave_dtype == F2_WAVE_I16                                                                                         \
+                   ? launch_group<int16_t, L>(ctx, (const int16_t*)d_wave, d_offsets, d_coefs, C, d_ulist, nutt, lpf, b0, a1,   \
+                                              d_env, d_uflag, tol, d_X, d_rho)                                                  \
+                   : launch_group<double, L>(ctx, (const double*)d_wave, d_offsets, d_coefs, C, d_ulist, nutt, lpf, b0, a1,      \
+                                             d_env, d_uflag, tol, d_X, d_rho);
+    switch (log2h) {
+        F2_SPEC_CASE(12)
+        F2_SPEC_CASE(13)
+        default:
+            return f2_fail(ctx, F2_ERR_UNSUPPORTED, "spectral path: length class 2^%d not built", log2h + 1);
+    }
+#undef F2_SPEC_CASE
+}

@@ -56,7 +56,7 @@ enum { F2_WAVE_I16 = 0, F2_WAVE_F64 = 1 };
 enum { F2_FFT_F32 = 0, F2_FFT_F64 = 1 };
 
 /* ---- library / context -------------------------------------------------------------------- */
-int f2_version(void);   /* 100 * major + minor; 101 added f2_eval_batch, 102 f2_host_alloc + F2_MEM_HOST_ASYNC */
+int f2_version(void);   /* 100 * major + minor; 101 added f2_eval_batch, 102 f2_host_alloc + F2_MEM_HOST_ASYNC, 103 f2_ctx_set_option */
 int f2_device_count(int* count);
 int f2_ctx_create(int device, f2_ctx** ctx);
 int f2_ctx_destroy(f2_ctx* ctx);
@@ -66,6 +66,21 @@ int f2_ctx_set_stream(f2_ctx* ctx, void* hip_stream);
 void* f2_ctx_get_stream(f2_ctx* ctx);
 /* text of the last error on this context (ctx == NULL: last context-less error) */
 const char* f2_last_error(f2_ctx* ctx);
+/* Per-context tuning switches (the reference has none: its only knobs are the CLI arguments). Unknown key:
+ * F2_ERR_INVALID. Keys (value -1 = decide from the batch, where stated):
+ *   "spectral"       1 (default) / 0   f2_filterbank_envelope_fused serves eligible utterances with the one-kernel
+ *                                      spectral path; 0 = always filterbank kernel + envelope kernel
+ *   "spectral_tol"   accuracy guard of that path (default 4e-6): relative residual that sends an utterance back
+ *   "k1_split"       -1 / 0 / K >= 2   time-split filterbank for small batches: auto / never / K segments
+ *   "k1_queue"       -1 / 0 / 1        unit queue of the filterbank for ragged batches
+ *   "k1_qwaves"      0 / n             waves of the queue launch (0 = from the batch)
+ *   "env_pair"       1 / 0             on-chip envelope kernel for rows of 32769..65536 samples
+ *   "env_plan4"      0 / 1             four-pass transform plan for every 8193..16384-sample row
+ * Read-only (f2_ctx_get_option): "spectral_flagged" = utterances of the last fused call that the spectral kernel's
+ * accuracy guard handed back to the two-kernel route (waits for the stream).
+ * Two contexts on two host threads choose independently. */
+int f2_ctx_set_option(f2_ctx* ctx, const char* key, double value);
+int f2_ctx_get_option(f2_ctx* ctx, const char* key, double* value);
 
 /* ---- device memory + timing helpers (so a host language needs no HIP binding of its own) ---- */
 int f2_dev_malloc(f2_ctx* ctx, size_t bytes, void** dptr);
@@ -85,7 +100,16 @@ int f2_event_elapsed_ms(f2_ctx* ctx, void* start, void* stop, float* ms); /* wai
 /* ---- per-kernel timing (HIP events recorded around every kernel launch on the context's stream) ----
  * Kernel ids: F2_K_* below. f2_prof_get waits for the stream, returns the number of launches of that
  * kernel since the last f2_prof_enable(ctx, 1) / f2_prof_reset and their summed device time. */
-enum { F2_K_FILTERBANK = 0, F2_K_ENVELOPE = 1, F2_K_GATHER = 2, F2_K_CNN = 3, F2_K_FUSED = 4, F2_K_COUNT = 5 };
+enum {
+    F2_K_FILTERBANK = 0,   /* k_erb_filterbank                                                       */
+    F2_K_ENVELOPE = 1,     /* k_envelope and its long-row variants                                   */
+    F2_K_GATHER = 2,
+    F2_K_CNN = 3,
+    F2_K_FUSED = 4,        /* k_spectral_envelope: filterbank + envelope of a row in ONE kernel      */
+    F2_K_SPECTRUM = 5,     /* k_utterance_spectrum: float64 transform of each utterance, once        */
+    F2_K_TAIL = 6,         /* k_tail_state: filter state at the end of each row                      */
+    F2_K_COUNT = 7
+};
 int f2_prof_enable(f2_ctx* ctx, int on);
 int f2_prof_reset(f2_ctx* ctx);
 int f2_prof_get(f2_ctx* ctx, int kernel_id, int* launches, float* total_ms);

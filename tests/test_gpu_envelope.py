@@ -158,13 +158,9 @@ def test_rows_of_32769_to_65536_samples_on_chip_and_four_step(n):
     env = np.empty(8 * int(offs[-1]))
     outs = {}
     for tag in ("pair", "four"):
-        if tag == "four":
-            os.environ["F2CNN_NO_PAIR"] = "1"
-        try:
+        with ctx.options(env_pair=1 if tag == "pair" else 0):
             ctx.filterbank_envelope_fused(flat, _lib.WAVE_I16, offs, coefs, 3, 8, True, 50.0, _lib.FFT_F32, env, None,
                                           _lib.MEM_HOST)
-        finally:
-            os.environ.pop("F2CNN_NO_PAIR", None)
         outs[tag] = [env[8 * offs[b]:8 * offs[b + 1]].reshape(8, -1).copy() for b in range(3)]
     for b, w in enumerate(waves):
         ref = orc.filter_and_envelope(w, coefs, True, 50)

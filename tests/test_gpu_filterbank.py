@@ -74,15 +74,8 @@ def test_bad_arguments():
 
 
 def _fb(waves, coefs, split):
-    old = os.environ.get("F2CNN_K1_SPLIT")
-    os.environ["F2CNN_K1_SPLIT"] = split
-    try:
+    with _lib.default_context().options(k1_split=int(split)):
         return filters.erb_filterbank_batch(waves, coefs)
-    finally:
-        if old is None:
-            del os.environ["F2CNN_K1_SPLIT"]
-        else:
-            os.environ["F2CNN_K1_SPLIT"] = old
 
 
 @pytest.mark.parametrize("C", [64, 128, 8])
@@ -111,20 +104,17 @@ def test_time_split_path_for_small_batches(C):
 
 
 def test_queue_mode_for_ragged_batches():
-    """Ragged batches hand their (utterance, channel group) units out longest first (F2CNN_K1_QUEUE=1 forces the
+    """Ragged batches hand their (utterance, channel group) units out longest first (option k1_queue = 1 forces the
     path that large ragged batches take by themselves): same bits as one fixed unit per wave."""
     coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
     rng = np.random.default_rng(11)
     waves = [orc.synth_utterance(100 + i, int(n)) for i, n in enumerate(rng.integers(40, 3000, size=37))]
     waves.append(np.zeros(0, np.int16))
-    os.environ["F2CNN_K1_SPLIT"] = "0"
-    try:
+    ctx = _lib.default_context()
+    with ctx.options(k1_split=0):
         plain = filters.erb_filterbank_batch(waves, coefs)
-        os.environ["F2CNN_K1_QUEUE"] = "1"
-        queued = filters.erb_filterbank_batch(waves, coefs)
-    finally:
-        os.environ.pop("F2CNN_K1_QUEUE", None)
-        del os.environ["F2CNN_K1_SPLIT"]
+        with ctx.options(k1_queue=1):
+            queued = filters.erb_filterbank_batch(waves, coefs)
     for a, b, w in zip(plain, queued, waves):
         assert a.shape == b.shape == (128, len(w))
         np.testing.assert_array_equal(a, b)
@@ -142,11 +132,9 @@ def test_rows_that_do_not_start_on_a_line(C, mode):
     coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
     lens = [1599, 1602, 33, 1601, 47, 3, 2050, 97, 1, 33001 if mode != "split" else 4099]
     waves = [orc.synth_utterance(300 + i, n) for i, n in enumerate(lens)]
-    env = {"plain": {"F2CNN_K1_SPLIT": "0", "F2CNN_K1_QUEUE": "0"}, "split": {"F2CNN_K1_SPLIT": "3"},
-           "queue": {"F2CNN_K1_SPLIT": "0", "F2CNN_K1_QUEUE": "1"}}[mode]
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    opts = {"plain": dict(k1_split=0, k1_queue=0), "split": dict(k1_split=3), "queue": dict(k1_split=0, k1_queue=1)}[mode]
+    # (the fused call below must run the filterbank kernel under test, not the spectral path)
+    with ctx.options(spectral=0, **opts):
         gfb = filters.erb_filterbank_batch(waves, coefs)
         # fused call: float32 hand-off (in the rows' own slots up to 32768 samples, compact scratch rows beyond)
         flat = np.concatenate(waves)
@@ -154,12 +142,6 @@ def test_rows_that_do_not_start_on_a_line(C, mode):
         envs = np.full(C * int(off[-1]), np.nan)
         ctx.filterbank_envelope_fused(flat, _lib.WAVE_I16, off, coefs, len(lens), C, False, 0.0, _lib.FFT_F32, envs, None,
                                       _lib.MEM_HOST)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
     for i, (w, g) in enumerate(zip(waves, gfb)):
         ref = orc.erb_filterbank(w, coefs)
         assert g.shape == ref.shape

@@ -44,12 +44,8 @@ def test_cfg2_filterbank_full_batch(corpus):
         assert chan_relerr(got, orc.erb_filterbank(waves[b], coefs[rows])) <= 1e-9
     # batching must not matter: utterance 255 alone gives the same bits as inside the batch when it runs the same
     # (serial) kernel, and the same values to float64 rounding through the time-split path a single utterance takes
-    import os
-    os.environ["F2CNN_K1_SPLIT"] = "0"
-    try:
+    with ctx.options(k1_split=0):
         alone = filters.erb_filterbank(waves[255], coefs)
-    finally:
-        del os.environ["F2CNN_K1_SPLIT"]
     np.testing.assert_array_equal(alone[rows], fetch_rows(ctx, d_gfb, 255, rows))
     assert chan_relerr(filters.erb_filterbank(waves[255], coefs)[rows], alone[rows]) <= 1e-11
     # no element left untouched anywhere in the 4.2 GB output (sum of a checksum per utterance is finite)

@@ -1,0 +1,99 @@
+"""Spectral filterbank + envelope kernel (f2cnn_amd/csrc/f2_spectral.hip) behind f2_filterbank_envelope_fused:
+parity with the oracle (reference: gammatone/filters.py:195-239 followed by scripts/processing/EnvelopeExtraction.py:51-67)
+and with the filterbank kernel + envelope kernel route, eligibility by length, and the accuracy guard's fallback."""
+import numpy as np
+import pytest
+
+import f2cnn_oracle as orc
+from f2cnn_amd import _lib
+from f2cnn_amd.gammatone import filters
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5      # per-channel max-norm, relative (north star)
+
+
+def chan_relerr(a, b):
+    return float((np.abs(a - b).max(axis=1) / np.abs(b).max(axis=1)).max())
+
+
+def fused(ctx, waves, coefs, lpf, cutoff=50.0, **opts):
+    C = coefs.shape[0]
+    offs = np.concatenate([[0], np.cumsum([len(w) for w in waves])]).astype(np.int64)
+    flat = np.concatenate(waves)
+    dtype = _lib.WAVE_I16 if flat.dtype == np.int16 else _lib.WAVE_F64
+    env = np.full(C * int(offs[-1]), np.nan)
+    with ctx.options(**opts):
+        ctx.filterbank_envelope_fused(flat, dtype, offs, coefs, len(waves), C, lpf, cutoff, _lib.FFT_F32, env, None,
+                                      _lib.MEM_HOST)
+        flagged = int(ctx.get_option("spectral_flagged"))
+    return [env[C * offs[b]:C * offs[b + 1]].reshape(C, -1) for b in range(len(waves))], flagged
+
+
+@pytest.mark.parametrize("lpf", [False, True])
+def test_ragged_batch_against_oracle_and_two_kernel_route(lpf):
+    """Lengths on both length classes the kernel serves (4097..8192, 8193..16384 samples), odd lengths, the shortest
+    padding it accepts (64 samples), and lengths it leaves to the two-kernel route (fewer padding samples, short and
+    long rows) in one batch; 128 channels."""
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    lens = [16000, 15999, 9000, 8193, 16320, 16321, 4097, 5000, 8128, 8129, 300, 16384, 20000, 1]
+    waves = [orc.synth_utterance(500 + i, n) for i, n in enumerate(lens)]
+    got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
+    old, _ = fused(ctx, waves, coefs, lpf, spectral=0)
+    assert flagged == 0
+    for w, g, o in zip(waves, got, old):
+        ref = orc.filter_and_envelope(w, coefs, lpf, 50)
+        assert g.shape == ref.shape
+        assert chan_relerr(g, ref) <= TOL, len(w)
+        assert chan_relerr(g, o) <= 4e-6, len(w)
+
+
+def test_float64_waves_and_small_tables():
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(9)
+    for C in (8, 64, 70):
+        coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
+        waves = [orc.synth_utterance(40 + i, n).astype(np.float64) + rng.standard_normal(n) for i, n in enumerate((12000, 6001))]
+        got, flagged = fused(ctx, waves, coefs, True, spectral=1)
+        assert flagged == 0
+        for w, g in zip(waves, got):
+            assert chan_relerr(g, orc.filter_and_envelope(w, coefs, True, 50)) <= TOL, C
+
+
+def test_signals_with_structure():
+    """Sine, DC, an impulse at the start, a strongly tilted spectrum (what speech looks like to the high channels)."""
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(3)
+    t = np.arange(16000) / 16000.0
+    tilt = lfilter([1.0], [1.0, -0.98], rng.standard_normal(16000))
+    imp = np.zeros(16000, np.int16)
+    imp[0] = 32767
+    waves = [np.round(10000 * np.sin(2 * np.pi * 1000 * t)).astype(np.int16), np.full(16000, 12000, np.int16), imp,
+             np.round(tilt / np.abs(tilt).max() * 30000).astype(np.int16),
+             np.round(20000 * np.sin(2 * np.pi * 120 * t) + 3 * rng.standard_normal(16000)).astype(np.int16)]
+    got, flagged = fused(ctx, waves, coefs, True, spectral=1)
+    assert flagged == 0
+    for i, (w, g) in enumerate(zip(waves, got)):
+        assert chan_relerr(g, orc.filter_and_envelope(w, coefs, True, 50)) <= TOL, i
+
+
+def test_accuracy_guard_sends_a_late_click_back():
+    """An isolated click in the last milliseconds: the low channels' output inside [0, n) is ~1e-6 of their ringing after
+    n, which the spectral formulation would resolve to ~5e-5 only. The kernel's guard flags the utterance on the device
+    and the two-kernel route recomputes it inside the same call; its neighbours in the batch stay on the spectral path."""
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    click = np.zeros(16000, np.int16)
+    click[15990] = 32767
+    waves = [orc.synth_utterance(1, 16000), click, orc.synth_utterance(2, 12000)]
+    for lpf in (False, True):
+        got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
+        assert flagged == 1
+        for w, g in zip(waves, got):
+            assert chan_relerr(g, orc.filter_and_envelope(w, coefs, lpf, 50)) <= TOL
+    # with the guard disabled the click really is out of tolerance on the spectral path (the guard is not idle)
+    got, flagged = fused(ctx, waves, coefs, False, spectral=1, spectral_tol=1.0)
+    assert flagged == 0
+    assert chan_relerr(got[1], orc.filter_and_envelope(click, coefs, False, 0)) > TOL

@@ -1,4 +1,4 @@
-"""Filterbank latency at small batch sizes: serial kernel (F2CNN_K1_SPLIT=0) against the time-split path."""
+"""Filterbank latency at small batch sizes: serial kernel (context option k1_split = 0) against the time-split path."""
 import os, sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
 from f2cnn_amd import _lib
@@ -13,8 +13,8 @@ for B, C in ((1, 64), (1, 128), (8, 128), (32, 128), (96, 128), (192, 128), (256
     d_w = ctx.malloc(waves.nbytes); ctx.h2d(d_w, waves); d_o = ctx.malloc(8 * C * N * B)
     res = {}
     for mode in ("0", ""):
-        if mode: os.environ["F2CNN_K1_SPLIT"] = mode
-        else: os.environ.pop("F2CNN_K1_SPLIT", None)
+        ctx.set_option("k1_split", int(mode) if mode else -1)
+        ctx.set_option("spectral", 0)
         f = lambda: ctx.filterbank_envelope_fused(d_w, 0, off, coefs, B, C, True, 50.0, 0, d_o, None, 1)
         f(); ctx.synchronize(); ctx.prof_enable(True)
         for _ in range(10): f()
