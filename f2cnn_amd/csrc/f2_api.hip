@@ -158,7 +158,7 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     for (auto& t : ctx->spec_tabs)
         for (f2_scratch* sc : {&t.hu, &t.e, &t.lgroup})
             if (sc->ptr) (void)hipFree(sc->ptr);
-    for (f2_scratch* sc : {&ctx->spec_x, &ctx->spec_rho, &ctx->spec_meta, &ctx->spec_uflag})
+    for (f2_scratch* sc : {&ctx->spec_x, &ctx->spec_rho, &ctx->spec_meta, &ctx->spec_uflag, &ctx->spec_lptab})
         if (sc->ptr) (void)hipFree(sc->ptr);
     for (auto& prec : ctx->tw_sp)
         for (f2_scratch& sc : prec)

@@ -70,6 +70,9 @@ struct f2_ctx {
     std::vector<int> spec_meta_host;      // what spec_meta currently holds
     size_t spec_last_B = 0;               // batch size of the last fused call that used the spectral kernel (0: none)
     f2_scratch tw_sp[2][16];              // its twiddle tables, [precision][log2 H]
+    f2_scratch spec_lptab;                // low-pass powers per thread (lowpass_pairs_store_tab) ...
+    double spec_lptab_a1 = 0.0;           // ... for this a1
+    int spec_lptab_nt = 0;                // ... and workgroup size
     // options (f2_ctx_set_option); -1 = decide from the batch
     int opt_spectral = 1;                 // route eligible utterances of the fused call through the spectral kernel
     float opt_spectral_tol = 4e-6f;       // accuracy guard: padding residual / row maximum that flags an utterance

@@ -50,22 +50,152 @@ using namespace f2fft;
 namespace {
 
 typedef float f2_f4 __attribute__((ext_vector_type(4)));
+#ifndef F2_SPEC_GB
+#define F2_SPEC_GB 16     // bins per load group of the spectrum phase: all 32 loads of a thread in flight (4, 8: measured slower)
+#endif
 
+// Diagnostic build only (-DF2_STAMPS): wave 0 of every workgroup records s_memrealtime (100 MHz) at the phase boundaries.
+#ifdef F2_STAMPS
+#define F2_SSTAMP(k)                                         \
+    do {                                                     \
+        __builtin_amdgcn_sched_barrier(0);                   \
+        sst[k] = __builtin_amdgcn_s_memrealtime();             \
+        __builtin_amdgcn_sched_barrier(0);                   \
+    } while (0)
+#else
+#define F2_SSTAMP(k) \
+    do {             \
+    } while (0)
+#endif
+
+// ---- first-order low-pass in the register layout of the transforms, constants from a table ----
+// Same decomposition as lowpass_pairs_store (f2_envelope_core.h: pair -> weighted DPP scan over the wave -> wave totals ->
+// block chain) for NBLK = 16 blocks of float pairs, rearranged for fewer vector instructions per row: every power of
+// q = -a1 a thread needs comes from a table built once per (cutoff, workgroup size) on the host instead of float64
+// square-and-multiply loops per row; each scan step is ONE v_fmac_f32 with the DPP lane move as its operand (the
+// compiler leaves v_mov_b32_dpp + v_fmac_f32 pairs behind); the chain over the wave totals AND over the blocks is run
+// once by the first sixteen threads (float64, a DPP scan over the sixteen block totals) instead of by every thread,
+// and the carries reach the others as floats.
+struct LowpassConsts {
+    float qf, b0f;            // q = -a1, b0
+    float g1, g2, g4, g8;     // q^2, q^4, q^8, q^16: multipliers of the row_shr 1/2/4/8 steps
+    double gw, gblk;          // q^128 (one wave of pairs), q^(2 NT) (one block)
+};
+
+template <int NT, int NBLK>
+constexpr size_t lowpass_tab_lds_bytes() {
+    return sizeof(float) * ((size_t)NBLK * NT + 2 * NBLK * (NT / 64) + NBLK);
+}
+
+// one step of the weighted scan on all blocks: sc[j] += g * lane_move(sc[j])
+#define F2_DPP_STEP(CTRL)                                                                                                    \
+    asm volatile("s_nop 1\n\t"                                                                                               \
+                 "v_fmac_f32_dpp %0, %0, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %1, %1, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %2, %2, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %3, %3, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %4, %4, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %5, %5, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %6, %6, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %7, %7, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %8, %8, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %9, %9, %16 " CTRL "\n\t"                                                                   \
+                 "v_fmac_f32_dpp %10, %10, %16 " CTRL "\n\t"                                                                 \
+                 "v_fmac_f32_dpp %11, %11, %16 " CTRL "\n\t"                                                                 \
+                 "v_fmac_f32_dpp %12, %12, %16 " CTRL "\n\t"                                                                 \
+                 "v_fmac_f32_dpp %13, %13, %16 " CTRL "\n\t"                                                                 \
+                 "v_fmac_f32_dpp %14, %14, %16 " CTRL "\n\t"                                                                 \
+                 "v_fmac_f32_dpp %15, %15, %16 " CTRL                                                                        \
+                 : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]), "+v"(sc[6]), "+v"(sc[7]),   \
+                   "+v"(sc[8]), "+v"(sc[9]), "+v"(sc[10]), "+v"(sc[11]), "+v"(sc[12]), "+v"(sc[13]), "+v"(sc[14]), "+v"(sc[15]) \
+                 : "v"(mult))
+
+// Thread t holds the envelope pairs (2m, 2m+1), m = t + NT jj (er[jj], ei[jj]); y[n] = q y[n-1] + b0 (e[n] + e[n-1]) from
+// zero state; float64 rows out as coalesced 16-byte stores. lptab[t] = {q^(2 (lane+1)), q^(2 t), (q^2)^((lane & 15) + 1),
+// (q^2)^((lane & 31) + 1)}. All threads call it, after a barrier that makes `smem` free.
+template <int NT, int NBLK>
+__device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK], const float (&ei)[NBLK], const LowpassConsts& K,
+                                                        const f2_f4* __restrict__ lptab, unsigned char* smem,
+                                                        double* __restrict__ y, int n, int tid) {
+    static_assert(NBLK == 16, "sixteen blocks: one DPP row chains them");
+    constexpr int NW = NT / 64;
+    float* e1s = reinterpret_cast<float*>(smem);   // [NBLK][NT] odd samples, for e[n-1]
+    float* wtot = e1s + NBLK * NT;                 // [NBLK][NW] zero-state value at the end of each wave
+    float* cwl = wtot + NBLK * NW;                 // [NBLK][NW] zero-state value of the block entering each wave
+    float* ycar = cwl + NBLK * NW;                 // [NBLK] true y entering each block
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int jj = 0; jj < NBLK; ++jj) e1s[jj * NT + tid] = ei[jj];
+    const f2_f4 tc = lptab[tid];
+    __syncthreads();
+    float u0[NBLK], u1[NBLK], sc[NBLK];
+#pragma unroll
+    for (int jj = 0; jj < NBLK; ++jj) {
+        const float eprev = tid > 0 ? e1s[jj * NT + tid - 1] : (jj > 0 ? e1s[(jj - 1) * NT + NT - 1] : 0.f);
+        u0[jj] = K.b0f * (er[jj] + eprev);
+        u1[jj] = K.b0f * (ei[jj] + er[jj]);
+        sc[jj] = fmaf(K.qf, u0[jj], u1[jj]);
+    }
+    {
+        float mult = K.g1;
+        F2_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+        mult = K.g2;
+        F2_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+        mult = K.g4;
+        F2_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+        mult = K.g8;
+        F2_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+        mult = tc.z;
+        F2_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+        mult = tc.w;
+        F2_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int jj = 0; jj < NBLK; ++jj) wtot[jj * NW + wv] = sc[jj];
+    }
+    __syncthreads();
+    if (tid < NBLK) {
+        // thread jj chains the NW wave totals of block jj (float64), then the sixteen block totals are chained by a
+        // weighted scan over the sixteen lanes: ycar[jj] = true y at the end of block jj - 1
+        double c = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) {
+            cwl[tid * NW + w2] = (float)c;
+            c = fma(K.gw, c, (double)wtot[tid * NW + w2]);
+        }
+        const double G1 = K.gblk, G2 = G1 * G1, G4 = G2 * G2, G8 = G4 * G4;
+        c = fma(G1, dpp_mov<0x111, 0xF>(c), c);
+        c = fma(G2, dpp_mov<0x112, 0xF>(c), c);
+        c = fma(G4, dpp_mov<0x114, 0xF>(c), c);
+        c = fma(G8, dpp_mov<0x118, 0xF>(c), c);
+        ycar[tid] = (float)dpp_mov<0x111, 0xF>(c);   // (lane 0 reads 0)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < NBLK; ++jj) {
+        const float cw = cwl[jj * NW + wv];
+        const float sin_ = fmaf(tc.x, cw, sc[jj]);            // zero-state value at the end of this pair
+        const float up = dpp_mov<0x138, 0xF>(sin_);            // wave_shr:1
+        const float sprev = lane > 0 ? up : cw;                // ... at the end of the previous pair
+        const float y0 = fmaf(K.qf, fmaf(tc.y, ycar[jj], sprev), u0[jj]);
+        const float y1 = fmaf(K.qf, y0, u1[jj]);
+        store_row_pair(y, n, 2 * (tid + NT * jj), (double)y0, (double)y1);
+    }
+}
+
+// (the read-only tables are separate __restrict__ kernel arguments: pointers inside a by-value struct carry no
+// no-alias information, and the wave-uniform reads among them would then go through the vector memory path)
 struct SpecParams {
-    const cpx<float>* X;      // [nutt][xpitch] spectra of the utterances of this launch, k = 0..H
-    int64_t xpitch;
-    const f2_f4* HU;          // [C][tpitch] {Hs.re, Hs.im, u.re, u.im}, Hs = (2/M) s N_1..N_4 u^4
-    int64_t tpitch;
-    const cpx<float>* E;      // [M] exp(-2 pi i q / M)
-    const float* rho;         // [nutt * C][8] digits r_0..r_3 of Q, scaled by (2/M) s
+    int64_t xpitch;           // X: [nutt][xpitch] spectra of the utterances of this launch, k = 0..H
+    int64_t tpitch;           // HU: [C][tpitch] {Hs.re, Hs.im, u.re, u.im}, Hs = (2/M) s N_1..N_4 u^4
     double* env;
-    const int64_t* offsets;
-    const int* ulist;         // utterances of this launch (device)
     int* uflag;               // [B] set to 1 when a row of the utterance fails the accuracy guard
     int C;
     int lpf;
-    double b0, a1;
+    LowpassConsts lp;
     float tol;
+    unsigned long long* stamps;   // diagnostic build only
 };
 
 // Y'(k) = (2/M) Y(k) of one bin
@@ -92,6 +222,17 @@ __device__ __forceinline__ cpx<float> spectral_bin(cpx<float> X, f2_f4 hu, cpx<f
     return {yr, yi};
 }
 
+// w_k of bin k = tid + j NB0: w_tid exp(-2 pi i j / (2 R0))  (NB0 / M = 1 / (2 R0))
+template <int R0, int J = 0>
+__device__ __forceinline__ cpx<float> bin_w(cpx<float> w0, int j) {
+    if constexpr (J < R0) {
+        if (j == J) return mulw<2 * R0, J>(w0);
+        return bin_w<R0, J + 1>(w0, j);
+    } else {
+        return w0;
+    }
+}
+
 // maximum over the wave, result valid in lane 63 (row_shr 1/2/4/8, row_bcast 15/31; values >= 0, missing lanes read 0)
 __device__ __forceinline__ float wave_max63(float v) {
     v = fmaxf(v, dpp_mov<0x111, 0xF>(v));
@@ -105,7 +246,10 @@ __device__ __forceinline__ float wave_max63(float v) {
 
 template <int LOG2H>
 __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float, LOG2H>())) void k_spectral_envelope(
-    SpecParams P, const cpx<float>* __restrict__ tw) {
+    SpecParams P, const cpx<float>* __restrict__ Xall /* utterance spectra */, const f2_f4* __restrict__ HUall,
+    const cpx<float>* __restrict__ E /* [M] exp(-2 pi i q / M) */, const float* __restrict__ rho_all /* [rows][8] digits of Q */,
+    const int64_t* __restrict__ offsets, const int* __restrict__ ulist, const f2_f4* __restrict__ lptab,
+    const cpx<float>* __restrict__ tw) {
     constexpr int NT = threads_for<float, LOG2H>();
     constexpr int H = 1 << LOG2H;
     constexpr int M = 2 * H;
@@ -117,7 +261,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     constexpr int PT = plan_points_per_thread(LOG2H, NT);
     constexpr int NBLK = ITER0 * R0;
     static_assert(PT == NBLK, "register shape");
-    constexpr size_t LP = lowpass_lds_bytes<float, NT, NBLK>();
+    constexpr size_t LP = lowpass_tab_lds_bytes<NT, NBLK>();
     constexpr int LDS_BYTES = (int)((size_t)CS * 8 > LP ? (size_t)CS * 8 : LP);
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     constexpr int TWL = plan_tw_lds_count(LOG2H);
@@ -128,36 +272,80 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     const int tid = threadIdx.x;
     const int u = blockIdx.x / P.C;
     const int c = blockIdx.x - u * P.C;
-    const int b = P.ulist[u];
-    const int64_t off = P.offsets[b];
-    const int n = (int)(P.offsets[b + 1] - off);
+    const int b = ulist[u];
+    const int64_t off = offsets[b];
+    const int n = (int)(offsets[b + 1] - off);
     double* __restrict__ y = P.env + ((size_t)P.C * (size_t)off + (size_t)c * (size_t)n);
-    const float* __restrict__ rho = P.rho + (size_t)blockIdx.x * 8;
-    const cpx<float>* __restrict__ Xu = P.X + (size_t)u * P.xpitch;
-    const f2_f4* __restrict__ HUc = P.HU + (size_t)c * P.tpitch;
-    const cpx<float>* __restrict__ E = P.E;
+    const float* __restrict__ rho = rho_all + (size_t)blockIdx.x * 8;
+    const cpx<float>* __restrict__ Xu = Xall + (size_t)u * P.xpitch;
+    const f2_f4* __restrict__ HUc = HUall + (size_t)c * P.tpitch;
 
+#ifdef F2_STAMPS
+    unsigned long long sst[8] = {0};
+#endif
+    F2_SSTAMP(0);
     for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2H, 1) + i];
     if (tid < 2) guard[tid] = 0u;
 
-    // 1. spectrum of the zero-padded row at this thread's bins k = tid + i NT + j NB0 (first-pass register layout)
+    // 1. spectrum of the zero-padded row at this thread's bins k = tid + j NB0 (first-pass register layout). Per bin two
+    //    loads (utterance spectrum, channel table); the two phase factors follow from one load each: w_k = w_tid e^{-2 pi i
+    //    j / 32} (compile-time constants) and w_k^n = w_tid^n (w_NB0^n)^j (wave-uniform factors, scalar loads). The bins
+    //    go in groups of GB with the next group's loads in flight - all 32 loads at once would need 96 registers.
+    static_assert(ITER0 == 1 && R0 == 16, "one radix-16 butterfly per thread in the first pass");
+    constexpr int GB = F2_SPEC_GB, NG = R0 / GB;
     cpx<float> yk[PT], v[PT];
     const unsigned zstep = ((unsigned)NB0 * (unsigned)n) & (M - 1);
+    cpx<float> w0 = E[tid];
+    cpx<float> z0 = E[__umul24((unsigned)tid, (unsigned)n) & (M - 1)];
+    const cpx<float> XH = Xu[H];     // Nyquist bin (wave-uniform addresses: scalar loads, issued up front)
+    const f2_f4 HUH = HUc[H];
+    cpx<float> Xl[2][GB];
+    f2_f4 Hl[2][GB];
+    // `kb` is laundered through an empty asm together with a result of each group, so that the loads of group g + 2
+    // cannot be issued before group g has been computed (the compiler would otherwise hoist all 32 loads and spill)
+    //  (unsigned lane offset + wave-uniform row pointers: one offset register serves every load)
+    unsigned kb = (unsigned)tid;
+#ifdef F2_KS_KO_LOADS   // knock-out (timing only, results wrong): table values from arithmetic instead of memory
+#define F2_KS_LOADX(ptr, idx) cpx<float>{1.0f + 1e-3f * (float)(idx), 1e-3f * (float)(idx)}
+#define F2_KS_LOADH(ptr, idx) f2_f4{1e-3f, 1e-4f * (float)(idx), 0.5f, 1e-3f * (float)(idx)}
+#else
+#define F2_KS_LOADX(ptr, idx) (ptr)[idx]
+#define F2_KS_LOADH(ptr, idx) (ptr)[idx]
+#endif
 #pragma unroll
-    for (int i = 0; i < ITER0; ++i) {
-        const int bf = tid + i * NT;
-        unsigned zi = __umul24((unsigned)bf, (unsigned)n) & (M - 1);   // (k n) mod M, k = bf + j NB0
+    for (int q = 0; q < GB; ++q) {
+        Xl[0][q] = F2_KS_LOADX(Xu + q * NB0, kb);
+        Hl[0][q] = F2_KS_LOADH(HUc + q * NB0, kb);
+    }
 #pragma unroll
-        for (int j = 0; j < R0; ++j) {
-            const int k = bf + j * NB0;
-            yk[i * R0 + j] = spectral_bin(Xu[k], HUc[k], E[k], E[zi], rho);
-            zi = (zi + zstep) & (M - 1);
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+                Xl[(g + 1) & 1][q] = F2_KS_LOADX(Xu + ((g + 1) * GB + q) * NB0, kb);
+                Hl[(g + 1) & 1][q] = F2_KS_LOADH(HUc + ((g + 1) * GB + q) * NB0, kb);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {
+            const int j = g * GB + q;
+            const cpx<float> zj = E[(j * zstep) & (M - 1)];                       // wave-uniform
+            yk[j] = spectral_bin(Xl[g & 1][q], Hl[g & 1][q], bin_w<R0>(w0, j), cmul(z0, zj), rho);
+        }
+        // (w0 / z0 pass through as well: the phase factors of a later group are then not formed ahead of time either)
+        if constexpr (GB == 4) {
+            asm volatile(""
+                         : "+v"(kb), "+v"(w0.re), "+v"(w0.im), "+v"(z0.re), "+v"(z0.im), "+v"(yk[g * GB].re), "+v"(yk[g * GB + 1].re),
+                           "+v"(yk[g * GB + 2].re), "+v"(yk[g * GB + 3].re));
+        } else {
+            asm volatile("" : "+v"(kb), "+v"(w0.re), "+v"(w0.im), "+v"(z0.re), "+v"(z0.im), "+v"(yk[g * GB].re), "+v"(yk[g * GB + GB - 1].re));
         }
     }
+    F2_SSTAMP(1);
     // k = 0 carries the Nyquist term: A_e(0) = A(0) + A(H), A_o(0) = A(0) - A(H) (both real); thread 0 keeps
     // (Y'(0), Y'(H)) in yk[0]
     if (tid == 0) {
-        const cpx<float> yh = spectral_bin(Xu[H], HUc[H], cpx<float>{-1.f, 0.f}, cpx<float>{(n & 1) ? -1.f : 1.f, 0.f}, rho);
+        const cpx<float> yh = spectral_bin(XH, HUH, cpx<float>{-1.f, 0.f}, cpx<float>{(n & 1) ? -1.f : 1.f, 0.f}, rho);
         yk[0] = {yk[0].re, yh.re};
     }
     // 2. even samples: conj(a[2m]) = DFT_H(conj(A_e) / M)
@@ -165,38 +353,42 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     for (int q = 0; q < PT; ++q) v[q] = {yk[q].re, -yk[q].im};
     if (tid == 0) v[0] = {0.5f * (yk[0].re + yk[0].im), 0.f};
     constexpr bool T0R = derive_tw0<float, LOG2H>();
-    fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid, v);
-    // the last pass left sample m = bf + j NB0 in v[i R0 + brev(j)]
+    F2_SSTAMP(2);
+    // (the thread index each transform works from is tied to its input: the first-pass twiddles - 30 registers once
+    // derived - and the LDS addresses are then not formed while the previous phase still needs the registers)
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e), "+v"(v[0].re), "+v"(v[PT - 1].im));
+    fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, v);
+    F2_SSTAMP(3);
+    // the last pass left sample m = tid + j NB0 in v[brev(j)]
     float er[NBLK], ei[NBLK];
 #pragma unroll
-    for (int i = 0; i < ITER0; ++i)
+    for (int j = 0; j < R0; ++j) {
+        const cpx<float> a = v[brev<R0>(j)];
+        er[j] = fsqrt(a.re * a.re + a.im * a.im);
+    }
+    const float pad_e = fabsf(v[brev<R0>(R0 - 1)].re);   // |Re a| of the last block's even sample
+    // 3. odd samples: conj(a[2m+1]) = DFT_H(conj(A_o) / M), conj(A_o(k)) = conj(A(k)) w_k  (w_k formed again from
+    //    w_tid: kept across the first transform they would cost 30 registers)
+    asm volatile("" : "+v"(w0.re), "+v"(w0.im));
 #pragma unroll
-        for (int j = 0; j < R0; ++j) {
-            const cpx<float> a = v[i * R0 + brev<R0>(j)];
-            er[i + ITER0 * j] = fsqrt(a.re * a.re + a.im * a.im);
-        }
-    const float pad_e = fabsf(v[(ITER0 - 1) * R0 + brev<R0>(R0 - 1)].re);   // |Re a| of the last block's even sample
-    // 3. odd samples: conj(a[2m+1]) = DFT_H(conj(A_o) / M), conj(A_o(k)) = conj(A(k)) w_k
-#pragma unroll
-    for (int i = 0; i < ITER0; ++i) {
-        const int bf = tid + i * NT;
-#pragma unroll
-        for (int j = 0; j < R0; ++j) {
-            const cpx<float> w = E[bf + j * NB0];
-            const cpx<float> a = yk[i * R0 + j];
-            v[i * R0 + j] = {a.re * w.re + a.im * w.im, a.re * w.im - a.im * w.re};
-        }
+    for (int j = 0; j < R0; ++j) {
+        const cpx<float> w = bin_w<R0>(w0, j);
+        const cpx<float> a = yk[j];
+        v[j] = {a.re * w.re + a.im * w.im, a.re * w.im - a.im * w.re};
     }
     if (tid == 0) v[0] = {0.5f * (yk[0].re - yk[0].im), 0.f};
-    fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid, v);
+    F2_SSTAMP(4);
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o), "+v"(v[0].re), "+v"(v[PT - 1].im));
+    fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_o, v);
+    F2_SSTAMP(5);
 #pragma unroll
-    for (int i = 0; i < ITER0; ++i)
-#pragma unroll
-        for (int j = 0; j < R0; ++j) {
-            const cpx<float> a = v[i * R0 + brev<R0>(j)];
-            ei[i + ITER0 * j] = fsqrt(a.re * a.re + a.im * a.im);
-        }
-    const float pad_o = fabsf(v[(ITER0 - 1) * R0 + brev<R0>(R0 - 1)].re);
+    for (int j = 0; j < R0; ++j) {
+        const cpx<float> a = v[brev<R0>(j)];
+        ei[j] = fsqrt(a.re * a.re + a.im * a.im);
+    }
+    const float pad_o = fabsf(v[brev<R0>(R0 - 1)].re);
     // 4. accuracy guard: block jj of this thread is the sample pair 2 (tid + NT jj), + 1. Inside [0, n) the row's
     //    maximum; in the padding region the REAL part of a (the zero-padded row itself: zero in exact arithmetic, while
     //    the imaginary part, the Hilbert transform of a time-limited signal, is not) - sampled in the last block, which
@@ -222,18 +414,24 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         atomicMax(&guard[0], __float_as_uint(gin));
         atomicMax(&guard[1], __float_as_uint(gout));
     }
+    F2_SSTAMP(6);
     // 5. stores (the last pass of the transform ended with a barrier after its LDS reads: smem is free)
     if (!P.lpf) {
 #pragma unroll
         for (int jj = 0; jj < NBLK; ++jj) store_row_pair(y, n, 2 * (tid + NT * jj), (double)er[jj], (double)ei[jj]);
         __syncthreads();
     } else {
-        lowpass_pairs_store<float, NT, NBLK>(er, ei, P.a1, P.b0, smem, y, n, tid);   // (contains barriers)
+        lowpass_pairs_store_tab<NT, NBLK>(er, ei, P.lp, lptab, smem, y, n, tid);   // (contains barriers)
     }
     if (tid == 0) {
         const float gi = __uint_as_float(guard[0]), go = __uint_as_float(guard[1]);
         if (go > P.tol * gi) P.uflag[b] = 1;
     }
+#ifdef F2_STAMPS
+    F2_SSTAMP(7);
+    if (tid == 0 && P.stamps)
+        for (int k = 0; k < 8; ++k) P.stamps[(size_t)blockIdx.x * 8 + k] = sst[k];
+#endif
 }
 
 // ---- X = DFT_M(x zero-padded), k = 0..H, float64 arithmetic, float32 out: one workgroup per utterance ----
@@ -545,6 +743,35 @@ static int spectral_tables(f2_ctx* ctx, int C, int log2h, f2_spec_tables** out) 
     return F2_OK;
 }
 
+// powers of q = -a1 every thread needs (lowpass_pairs_store_tab), cached per a1
+static int lowpass_table(f2_ctx* ctx, double a1, double b0, int nt, LowpassConsts* K) {
+    const long double q = -(long double)a1;
+    K->qf = (float)q;
+    K->b0f = (float)b0;
+    K->g1 = (float)powl(q, 2);
+    K->g2 = (float)powl(q, 4);
+    K->g4 = (float)powl(q, 8);
+    K->g8 = (float)powl(q, 16);
+    K->gw = (double)powl(q, 128);
+    K->gblk = (double)powl(q, 2 * nt);
+    constexpr int TMAX = 1024;   // the per-thread entries do not depend on the workgroup size: one table serves all
+    if (ctx->spec_lptab.ptr && ctx->spec_lptab_a1 == a1 && ctx->spec_lptab_nt == TMAX) return F2_OK;
+    std::vector<float> tab((size_t)TMAX * 4);
+    for (int t = 0; t < TMAX; ++t) {
+        const int lane = t & 63;
+        tab[4 * (size_t)t] = (float)powl(q, 2 * (lane + 1));
+        tab[4 * (size_t)t + 1] = (float)powl(q, 2 * t);
+        tab[4 * (size_t)t + 2] = (float)powl(q, 2 * ((lane & 15) + 1));
+        tab[4 * (size_t)t + 3] = (float)powl(q, 2 * ((lane & 31) + 1));
+    }
+    F2_TRY(f2_reserve(ctx, ctx->spec_lptab, sizeof(float) * tab.size()));
+    F2_HIP(ctx, hipMemcpyAsync(ctx->spec_lptab.ptr, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `tab` is a local (one-time per cutoff)
+    ctx->spec_lptab_a1 = a1;
+    ctx->spec_lptab_nt = TMAX;
+    return F2_OK;
+}
+
 template <typename WaveT, int LOG2H>
 static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offsets, const double* d_coefs, int C,
                         const int* d_ulist, int nutt, int lpf, double b0, double a1, double* d_env, int* d_uflag, float tol,
@@ -569,26 +796,50 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_TAIL));
     SpecParams P;
-    P.X = d_X;
     P.xpitch = xpitch;
-    P.HU = (const f2_f4*)tab->hu.ptr;
     P.tpitch = tab->tpitch;
-    P.E = (const cpx<float>*)tab->e.ptr;
-    P.rho = d_rho;
     P.env = d_env;
-    P.offsets = d_offsets;
-    P.ulist = d_ulist;
     P.uflag = d_uflag;
     P.C = C;
     P.lpf = lpf;
-    P.b0 = b0;
-    P.a1 = a1;
+    F2_TRY(lowpass_table(ctx, a1, b0, threads_for<float, LOG2H>(), &P.lp));
     P.tol = tol;
+    P.stamps = nullptr;
+#ifdef F2_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    const size_t nstamp = (size_t)nutt * C * 8;
+    if (!d_stamps) F2_HIP(ctx, hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 8 * 128 * 2048));
+    if (nstamp <= (size_t)8 * 128 * 2048) P.stamps = d_stamps;
+#endif
     F2_TRY(f2_prof_begin(ctx, F2_K_FUSED));
     hipLaunchKernelGGL((k_spectral_envelope<LOG2H>), dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, LOG2H>()), 0,
-                       ctx->stream, P, (const cpx<float>*)ctx->tw_sp[0][LOG2H].ptr);
+                       ctx->stream, P, (const cpx<float>*)d_X, (const f2_f4*)tab->hu.ptr, (const cpx<float>*)tab->e.ptr,
+                       (const float*)d_rho, d_offsets, d_ulist, (const f2_f4*)ctx->spec_lptab.ptr,
+                       (const cpx<float>*)ctx->tw_sp[0][LOG2H].ptr);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_FUSED));
+#ifdef F2_STAMPS
+    if (P.stamps) {
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<unsigned long long> h(nstamp);
+        F2_HIP(ctx, hipMemcpy(h.data(), d_stamps, sizeof(unsigned long long) * nstamp, hipMemcpyDeviceToHost));
+        double acc[8] = {0};
+        const size_t rows = (size_t)nutt * C;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double life = 0;
+        for (size_t r = 0; r < rows; ++r) {
+            for (int k = 1; k < 8; ++k) acc[k] += (double)(h[r * 8 + k] - h[r * 8 + k - 1]);
+            t0 = std::min(t0, h[r * 8]);
+            t1 = std::max(t1, h[r * 8 + 7]);
+            life += (double)(h[r * 8 + 7] - h[r * 8]);
+        }
+        static const char* names[8] = {"", "spectrum", "nyquist+conj", "fft even", "mag+odd input", "fft odd", "mag+guard", "lpf+stores"};
+        fprintf(stderr, "[stamps KS] mean ticks (10 ns) per workgroup:");
+        for (int k = 1; k < 8; ++k) fprintf(stderr, " %s=%.0f", names[k], acc[k] / rows);
+        fprintf(stderr, "\n[stamps KS] mean workgroup lifetime %.1f ticks, kernel span %.0f ticks, workgroups alive at once %.1f\n",
+                life / rows, (double)(t1 - t0), life / (double)(t1 - t0));
+    }
+#endif
     return F2_OK;
 }
 

@@ -11,6 +11,7 @@ import bench
 B, C, N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, 128, 16000
 lpf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = _lib.Context(0)
+ctx.set_option("spectral", int(sys.argv[3]) if len(sys.argv) > 3 else 1)   # 0: stamps of the filterbank kernel + envelope kernel route
 coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100))
 waves = bench.synth_batch(2027, 0, B, N)
 off = np.arange(B + 1, dtype=np.int64) * N
