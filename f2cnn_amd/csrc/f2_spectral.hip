@@ -68,6 +68,32 @@ typedef float f2_f4 __attribute__((ext_vector_type(4)));
     } while (0)
 #endif
 
+// ---- row stores through a buffer descriptor with an explicit cache policy ----
+// The envelopes are written once and never read by this kernel, 128 KB per row. Stored with the default policy (or
+// "nt") the lines stay in the XCD's L2 until evicted and push out the tables every workgroup of the XCD re-reads (2 MB of
+// channel tables per XCD + the utterance spectra against 4 MB of L2: measured, half of the table reads then miss L2 and
+// the spectrum phase waits on the fabric). sc1 = write through and drop the line (MI355X_MICROARCH.md, store flavours).
+#ifndef F2_KS_CGROUP
+#define F2_KS_CGROUP 32
+#endif
+#ifndef F2_KS_STORE_AUX
+#define F2_KS_STORE_AUX 2    // raw buffer store cache policy bits: 0 default, 1 sc0, 2 nt, 16 sc1 (measured: nt 6.74, sc1 6.87, default 7.10 ms)
+#endif
+typedef unsigned int f2_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int f2_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer(double* y, int n) {
+    return __builtin_amdgcn_make_buffer_rsrc(y, 0, n * 8, 0x00020000);
+}
+// envelope samples i0, i0 + 1 of a row of n samples
+__device__ __forceinline__ void store_row_pair_buf(__amdgpu_buffer_rsrc_t r, int n, int i0, double a, double b) {
+    if (i0 + 1 < n) {
+        const f2_d2 v = {a, b};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(f2_u4, v), r, i0 * 8, 0, F2_KS_STORE_AUX);
+    } else if (i0 < n) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f2_u2, a), r, i0 * 8, 0, F2_KS_STORE_AUX);
+    }
+}
+
 // ---- first-order low-pass in the register layout of the transforms, constants from a table ----
 // Same decomposition as lowpass_pairs_store (f2_envelope_core.h: pair -> weighted DPP scan over the wave -> wave totals ->
 // block chain) for NBLK = 16 blocks of float pairs, rearranged for fewer vector instructions per row: every power of
@@ -124,6 +150,7 @@ __device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK],
     float* cwl = wtot + NBLK * NW;                 // [NBLK][NW] zero-state value of the block entering each wave
     float* ycar = cwl + NBLK * NW;                 // [NBLK] true y entering each block
     const int lane = tid & 63, wv = tid >> 6;
+    const __amdgpu_buffer_rsrc_t yb = row_buffer(y, n);
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) e1s[jj * NT + tid] = ei[jj];
     const f2_f4 tc = lptab[tid];
@@ -180,7 +207,7 @@ __device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK],
         const float sprev = lane > 0 ? up : cw;                // ... at the end of the previous pair
         const float y0 = fmaf(K.qf, fmaf(tc.y, ycar[jj], sprev), u0[jj]);
         const float y1 = fmaf(K.qf, y0, u1[jj]);
-        store_row_pair(y, n, 2 * (tid + NT * jj), (double)y0, (double)y1);
+        store_row_pair_buf(yb, n, 2 * (tid + NT * jj), (double)y0, (double)y1);
     }
 }
 
@@ -192,6 +219,7 @@ struct SpecParams {
     double* env;
     int* uflag;               // [B] set to 1 when a row of the utterance fails the accuracy guard
     int C;
+    int nutt;
     int lpf;
     LowpassConsts lp;
     float tol;
@@ -270,15 +298,33 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     cpx<float>* lds = reinterpret_cast<cpx<float>*>(smem);
 
     const int tid = threadIdx.x;
-    const int u = blockIdx.x / P.C;
-    const int c = blockIdx.x - u * P.C;
+    // Rows in the order (channel group of CG channels, utterance, channel in the group): the workgroups in flight then
+    // share CG channel tables instead of C (workgroup b runs on XCD b % 8: CG / 8 tables of 128 KB per XCD's L2) while an
+    // utterance's spectrum is still used by CG consecutive workgroups. Measured on 1000 x 1 s, 128 channels: 6.54 ms
+    // with CG = 32 against 6.71 ms with the plain (utterance, channel) order.
+    int u, c;
+    {
+        constexpr int CG = F2_KS_CGROUP;
+        const int nfull = P.C / CG, per = P.nutt * CG;
+        const int cg = min((int)(blockIdx.x / per), nfull);          // the last group may be partial
+        const int rr = blockIdx.x - cg * per;
+        const int gsz = cg < nfull ? CG : P.C - nfull * CG;
+        u = rr / gsz;
+        c = cg * CG + (rr - u * gsz);
+    }
+    const int row_id = u * P.C + c;
     const int b = ulist[u];
     const int64_t off = offsets[b];
     const int n = (int)(offsets[b + 1] - off);
     double* __restrict__ y = P.env + ((size_t)P.C * (size_t)off + (size_t)c * (size_t)n);
-    const float* __restrict__ rho = rho_all + (size_t)blockIdx.x * 8;
+    const float* __restrict__ rho = rho_all + (size_t)row_id * 8;
+#ifdef F2_KS_HOT_TABLES   // knock-out (timing only): every row reads utterance 0's spectrum and channel 0's table
+    const cpx<float>* __restrict__ Xu = Xall;
+    const f2_f4* __restrict__ HUc = HUall;
+#else
     const cpx<float>* __restrict__ Xu = Xall + (size_t)u * P.xpitch;
     const f2_f4* __restrict__ HUc = HUall + (size_t)c * P.tpitch;
+#endif
 
 #ifdef F2_STAMPS
     unsigned long long sst[8] = {0};
@@ -331,6 +377,13 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
             const int j = g * GB + q;
             const cpx<float> zj = E[(j * zstep) & (M - 1)];                       // wave-uniform
             yk[j] = spectral_bin(Xl[g & 1][q], Hl[g & 1][q], bin_w<R0>(w0, j), cmul(z0, zj), rho);
+#ifdef F2_STAMPS
+            if (j == 0 || j == 7) {
+                asm volatile("s_nop 0" : "+v"(yk[j].re), "+v"(yk[j].im));
+                sst[j == 0 ? 1 : 2] = __builtin_amdgcn_s_memrealtime();
+                asm volatile("s_nop 0" : "+v"(yk[j].re));
+            }
+#endif
         }
         // (w0 / z0 pass through as well: the phase factors of a later group are then not formed ahead of time either)
         if constexpr (GB == 4) {
@@ -341,7 +394,11 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
             asm volatile("" : "+v"(kb), "+v"(w0.re), "+v"(w0.im), "+v"(z0.re), "+v"(z0.im), "+v"(yk[g * GB].re), "+v"(yk[g * GB + GB - 1].re));
         }
     }
-    F2_SSTAMP(1);
+#ifdef F2_STAMPS
+    asm volatile("s_nop 0" : "+v"(yk[15].re), "+v"(yk[15].im));
+    sst[3] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_nop 0" : "+v"(yk[15].re));
+#endif
     // k = 0 carries the Nyquist term: A_e(0) = A(0) + A(H), A_o(0) = A(0) - A(H) (both real); thread 0 keeps
     // (Y'(0), Y'(H)) in yk[0]
     if (tid == 0) {
@@ -353,13 +410,11 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     for (int q = 0; q < PT; ++q) v[q] = {yk[q].re, -yk[q].im};
     if (tid == 0) v[0] = {0.5f * (yk[0].re + yk[0].im), 0.f};
     constexpr bool T0R = derive_tw0<float, LOG2H>();
-    F2_SSTAMP(2);
     // (the thread index each transform works from is tied to its input: the first-pass twiddles - 30 registers once
     // derived - and the LDS addresses are then not formed while the previous phase still needs the registers)
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e), "+v"(v[0].re), "+v"(v[PT - 1].im));
     fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, v);
-    F2_SSTAMP(3);
     // the last pass left sample m = tid + j NB0 in v[brev(j)]
     float er[NBLK], ei[NBLK];
 #pragma unroll
@@ -417,8 +472,9 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     F2_SSTAMP(6);
     // 5. stores (the last pass of the transform ended with a barrier after its LDS reads: smem is free)
     if (!P.lpf) {
+        const __amdgpu_buffer_rsrc_t yb = row_buffer(y, n);
 #pragma unroll
-        for (int jj = 0; jj < NBLK; ++jj) store_row_pair(y, n, 2 * (tid + NT * jj), (double)er[jj], (double)ei[jj]);
+        for (int jj = 0; jj < NBLK; ++jj) store_row_pair_buf(yb, n, 2 * (tid + NT * jj), (double)er[jj], (double)ei[jj]);
         __syncthreads();
     } else {
         lowpass_pairs_store_tab<NT, NBLK>(er, ei, P.lp, lptab, smem, y, n, tid);   // (contains barriers)
@@ -801,6 +857,7 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
     P.env = d_env;
     P.uflag = d_uflag;
     P.C = C;
+    P.nutt = nutt;
     P.lpf = lpf;
     F2_TRY(lowpass_table(ctx, a1, b0, threads_for<float, LOG2H>(), &P.lp));
     P.tol = tol;
@@ -833,7 +890,7 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
             t1 = std::max(t1, h[r * 8 + 7]);
             life += (double)(h[r * 8 + 7] - h[r * 8]);
         }
-        static const char* names[8] = {"", "spectrum", "nyquist+conj", "fft even", "mag+odd input", "fft odd", "mag+guard", "lpf+stores"};
+        static const char* names[8] = {"", "bin 0 ready", "bin 7 ready", "bin 15 ready", "fft even+mag+odd input", "fft odd", "mag+guard", "lpf+stores"};
         fprintf(stderr, "[stamps KS] mean ticks (10 ns) per workgroup:");
         for (int k = 1; k < 8; ++k) fprintf(stderr, " %s=%.0f", names[k], acc[k] / rows);
         fprintf(stderr, "\n[stamps KS] mean workgroup lifetime %.1f ticks, kernel span %.0f ticks, workgroups alive at once %.1f\n",

@@ -35,13 +35,20 @@ def test_default_workload_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     # roofline by the bytes the kernel must move, the hand-off only in moved_GBps; step-level fraction
-    assert r["kernel"] in d["kernels"] and r["moved_GBps"] >= r["achieved"]      # (at 96 utterances K1 is latency-bound)
-    k2 = d["kernels"]["k_envelope"]
-    assert k2["required_bytes_per_step"] == 8 * 128 * 96 * 16000 and k2["moved_GBps"] == pytest.approx(1.5 * k2["required_GBps"], rel=1e-3)
+    assert r["kernel"] in d["kernels"] and r["moved_GBps"] >= r["achieved"]
+    # the 1 s rows run the one-kernel spectral route: no hand-off, so what it moves is what it must move
+    ks = d["kernels"]["k_spectral_envelope"]
+    assert r["kernel"] == "k_spectral_envelope" and d["config"]["utterances_sent_back_by_the_accuracy_guard"] == 0
+    assert ks["required_bytes_per_step"] == 8 * 128 * 96 * 16000 and ks["moved_GBps"] == pytest.approx(ks["required_GBps"], rel=1e-3)
+    assert {"k_utterance_spectrum", "k_tail_state"} <= set(d["kernels"])
     need = (2 + 8 * 128) * 96 * 16000
     assert r["step"]["algorithmic_bytes"] == need
     assert abs(r["step"]["achieved"] - need / (d["ms_per_step"] / 1e3) / 1e9) / r["step"]["achieved"] < 0.02
-    assert d["kernels"]["k_erb_filterbank"]["f64_TFLOPps"] > 0
+    # the reference-precision block still runs filterbank kernel -> envelope kernel (float64 hand-off: 2x the required bytes)
+    k64 = d["blocks"]["cfg3_fft_f64"]["kernels"]
+    assert k64["k_envelope"]["moved_GBps"] == pytest.approx(2.0 * k64["k_envelope"]["required_GBps"], rel=1e-3)
+    assert k64["k_erb_filterbank"]["f64_TFLOPps"] > 0
+    assert d["scale"]["workload"] == "cfg5" and d["scale"]["value"] == d["blocks"]["cfg5"]["value"] and d["value_with_cnn"] > 0
     # the other configurations ride along in the default single-GPU line
     b = d["blocks"]
     assert set(b) >= {"cfg3_fft_f64", "cfg5", "cfg5_ragged", "cfg1", "cfg4", "end_to_end"}
