@@ -156,9 +156,9 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     if (ctx->handoff.ptr) (void)hipFree(ctx->handoff.ptr);
     if (ctx->handoff_off.ptr) (void)hipFree(ctx->handoff_off.ptr);
     for (auto& t : ctx->spec_tabs)
-        for (f2_scratch* sc : {&t.hu, &t.e, &t.lgroup})
+        for (f2_scratch* sc : {&t.hu, &t.e, &t.lgroup, &t.e64})
             if (sc->ptr) (void)hipFree(sc->ptr);
-    for (f2_scratch* sc : {&ctx->spec_x, &ctx->spec_rho, &ctx->spec_meta, &ctx->spec_uflag, &ctx->spec_lptab})
+    for (f2_scratch* sc : {&ctx->spec_x, &ctx->spec_rho, &ctx->spec_xpart, &ctx->spec_meta, &ctx->spec_uflag, &ctx->spec_lptab})
         if (sc->ptr) (void)hipFree(sc->ptr);
     for (auto& prec : ctx->tw_sp)
         for (f2_scratch& sc : prec)

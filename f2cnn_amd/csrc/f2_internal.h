@@ -22,10 +22,10 @@ struct f2_spec_tables {
     int log2h = 0, C = 0;
     std::vector<double> coefs;
     int64_t tpitch = 0;
-    f2_scratch hu, e, lgroup;
+    f2_scratch hu, e, lgroup, e64;
 };
-#define F2_SPECTRAL_MIN_LOG2H 12   // rows of 4097 ... 16384 samples
-#define F2_SPECTRAL_MAX_LOG2H 13
+#define F2_SPECTRAL_MIN_LOG2H 12   // rows of 4097 ... 32768 samples
+#define F2_SPECTRAL_MAX_LOG2H 14
 
 struct f2_ctx {
     int device = 0;
@@ -66,6 +66,7 @@ struct f2_ctx {
     // spectral path (f2_spectral.hip)
     std::vector<f2_spec_tables> spec_tabs;
     f2_scratch spec_x, spec_rho;          // utterance spectra, per-row digits of the launch in flight
+    f2_scratch spec_xpart;                // float64 partial spectra of decimated (long) utterances
     f2_scratch spec_meta, spec_uflag;     // [initial flags (B) | utterance lists]; the flags the kernels update
     std::vector<int> spec_meta_host;      // what spec_meta currently holds
     size_t spec_last_B = 0;               // batch size of the last fused call that used the spectral kernel (0: none)

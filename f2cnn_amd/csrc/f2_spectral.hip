@@ -490,15 +490,23 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
 #endif
 }
 
-// ---- X = DFT_M(x zero-padded), k = 0..H, float64 arithmetic, float32 out: one workgroup per utterance ----
+// ---- X = DFT_M(x zero-padded), k = 0..H, float64 arithmetic, float32 out ----
 // (float64: the float32 rounding of a transform is relative to the LOUDEST band of the utterance; a channel that sits
 // 60 dB below it - speech above 4 kHz - would inherit 1e-4 of its own level.)
-template <typename WaveT, int LOG2H>
-__global__ __launch_bounds__((threads_for<double, LOG2H>())) void k_utterance_spectrum(const WaveT* __restrict__ wave,
-                                                                                     const int64_t* __restrict__ offsets,
-                                                                                     const int* __restrict__ ulist,
-                                                                                     cpx<float>* __restrict__ X, int64_t xpitch,
-                                                                                     const cpx<double>* __restrict__ tw) {
+// One workgroup transforms one real sequence of 2 HS samples as HS packed complex points in LDS (HS <= 8192 in
+// float64). Utterances padded to M = 2 HS go straight to the float32 table (LOGD = 0). Longer ones (M = 2^LOGD 2 HS) are
+// decimated in time: workgroup (utterance, p) transforms x_p[m] = x[D m + p] and leaves its float64 spectrum
+// X_p(k), k = 0..HS; k_spectrum_combine then forms X(k) = sum_p W_M^(p k) X_p(k mod 2 HS) (X_p is 2 HS-periodic and
+// conjugate-symmetric), k = 0..M/2.
+template <typename WaveT, int LOG2HS, int LOGD>
+__global__ __launch_bounds__((threads_for<double, LOG2HS>())) void k_utterance_spectrum(const WaveT* __restrict__ wave,
+                                                                                      const int64_t* __restrict__ offsets,
+                                                                                      const int* __restrict__ ulist,
+                                                                                      cpx<float>* __restrict__ X, int64_t xpitch,
+                                                                                      cpx<double>* __restrict__ Xpart,
+                                                                                      const cpx<double>* __restrict__ tw) {
+    constexpr int LOG2H = LOG2HS;
+    constexpr int D = 1 << LOGD;
     constexpr int NT = threads_for<double, LOG2H>();
     constexpr int H = 1 << LOG2H;
     constexpr int CS = cpad_size(H);
@@ -510,13 +518,13 @@ __global__ __launch_bounds__((threads_for<double, LOG2H>())) void k_utterance_sp
     __shared__ __attribute__((aligned(16))) cpx<double> lds[CS];
     constexpr int TWL = plan_tw_lds_count(LOG2H);
     __shared__ __attribute__((aligned(16))) cpx<double> twl[TWL > 0 ? TWL : 1];
-    const cpx<double>* __restrict__ V = tw + plan_tw_total(LOG2H);   // exp(-2 pi i k / M), k <= H/2
+    const cpx<double>* __restrict__ V = tw + plan_tw_total(LOG2H);   // exp(-2 pi i k / (2 H)), k <= H/2
     const int tid = threadIdx.x;
-    const int b = ulist[blockIdx.x];
+    const int ul = blockIdx.x >> LOGD, ph = blockIdx.x & (D - 1);
+    const int b = ulist[ul];
     const int64_t off = offsets[b];
     const int n = (int)(offsets[b + 1] - off);
     const WaveT* __restrict__ x = wave + off;
-    cpx<float>* __restrict__ Xo = X + (size_t)blockIdx.x * xpitch;
     for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2H, 1) + i];
     cpx<double> v[PT];
 #pragma unroll
@@ -525,27 +533,61 @@ __global__ __launch_bounds__((threads_for<double, LOG2H>())) void k_utterance_sp
         if (FULL0 || bf < NB0) {
 #pragma unroll
             for (int j = 0; j < R0; ++j) {
-                const int i0 = 2 * (bf + j * NB0);
-                v[i * R0 + j] = {i0 < n ? (double)x[i0] : 0.0, i0 + 1 < n ? (double)x[i0 + 1] : 0.0};
+                const int i0 = D * 2 * (bf + j * NB0) + ph, i1 = i0 + D;   // samples 2 m' and 2 m' + 1 of x_p
+                v[i * R0 + j] = {i0 < n ? (double)x[i0] : 0.0, i1 < n ? (double)x[i1] : 0.0};
             }
         }
     }
-    fft_all<double, LOG2H, false, PT, NT, false>(lds, tw, twl, tid, v);   // Z = FFT_H(x[2m] + i x[2m+1]) in lds[cpad(k)]
-    // X(k) = E(k) + w_k O(k), E = (Z(k) + conj Z(H-k)) / 2, O = (Z(k) - conj Z(H-k)) / (2i); X(H-k) = conj(E - w_k O)
+    fft_all<double, LOG2H, false, PT, NT, false>(lds, tw, twl, tid, v);   // Z = FFT_H(x_p[2m] + i x_p[2m+1]) in lds[cpad(k)]
+    // X_p(k) = E(k) + w_k O(k), E = (Z(k) + conj Z(H-k)) / 2, O = (Z(k) - conj Z(H-k)) / (2i); X_p(H-k) = conj(E - w_k O)
+    cpx<float>* __restrict__ Xo = X + (size_t)ul * xpitch;
+    cpx<double>* __restrict__ Xp = Xpart + (size_t)blockIdx.x * (H + 1);
     for (int k = 1 + tid; k <= H / 2; k += NT) {
         const cpx<double> zk = lds[cpad(k)], zh = lds[cpad(H - k)];
         const cpx<double> e = {0.5 * (zk.re + zh.re), 0.5 * (zk.im - zh.im)};
         const cpx<double> o = {0.5 * (zk.im + zh.im), -0.5 * (zk.re - zh.re)};
         const cpx<double> w = V[k];
         const cpx<double> wo = {o.re * w.re - o.im * w.im, o.re * w.im + o.im * w.re};
-        Xo[k] = {(float)(e.re + wo.re), (float)(e.im + wo.im)};
-        Xo[H - k] = {(float)(e.re - wo.re), (float)(-(e.im - wo.im))};
+        if constexpr (LOGD == 0) {
+            Xo[k] = {(float)(e.re + wo.re), (float)(e.im + wo.im)};
+            Xo[H - k] = {(float)(e.re - wo.re), (float)(-(e.im - wo.im))};
+        } else {
+            Xp[k] = {e.re + wo.re, e.im + wo.im};
+            Xp[H - k] = {e.re - wo.re, -(e.im - wo.im)};
+        }
     }
     if (tid == 0) {
         const cpx<double> z0 = lds[cpad(0)];
-        Xo[0] = {(float)(z0.re + z0.im), 0.f};
-        Xo[H] = {(float)(z0.re - z0.im), 0.f};
+        if constexpr (LOGD == 0) {
+            Xo[0] = {(float)(z0.re + z0.im), 0.f};
+            Xo[H] = {(float)(z0.re - z0.im), 0.f};
+        } else {
+            Xp[0] = {z0.re + z0.im, 0.0};
+            Xp[H] = {z0.re - z0.im, 0.0};
+        }
     }
+}
+
+// X(k) = sum_p W_M^(p k) X_p(k mod 2 HS), k = 0..M/2 = D HS; e64[q] = exp(-2 pi i q / M), q < M (float64)
+template <int LOG2HS, int LOGD>
+__global__ __launch_bounds__(256) void k_spectrum_combine(const cpx<double>* __restrict__ Xpart, const cpx<double>* __restrict__ e64,
+                                                          cpx<float>* __restrict__ X, int64_t xpitch) {
+    constexpr int D = 1 << LOGD, HS = 1 << LOG2HS, H = D * HS, M = 2 * H;
+    const int ul = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k > H) return;
+    const int kk = k & (2 * HS - 1);
+    double re = 0.0, im = 0.0;
+#pragma unroll
+    for (int ph = 0; ph < D; ++ph) {
+        const cpx<double>* __restrict__ Xp = Xpart + ((size_t)ul * D + ph) * (HS + 1);
+        cpx<double> xp = kk <= HS ? Xp[kk] : Xp[2 * HS - kk];
+        if (kk > HS) xp.im = -xp.im;
+        const cpx<double> w = e64[(ph * k) & (M - 1)];
+        re += xp.re * w.re - xp.im * w.im;
+        im += xp.re * w.im + xp.im * w.re;
+    }
+    X[(size_t)ul * xpitch + k] = {(float)re, (float)im};
 }
 
 // ---- state of the cascade at the end of every row -> digits of Q (float64), one wave = 64 channels of an utterance ----
@@ -738,7 +780,8 @@ static int spectral_tables(f2_ctx* ctx, int C, int log2h, f2_spec_tables** out) 
         }
     if (ctx->spec_tabs.size() >= 6) {   // a handful of (table, length class) pairs at most; drop the oldest
         F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (f2_scratch* s : {&ctx->spec_tabs.front().hu, &ctx->spec_tabs.front().e, &ctx->spec_tabs.front().lgroup})
+        for (f2_scratch* s : {&ctx->spec_tabs.front().hu, &ctx->spec_tabs.front().e, &ctx->spec_tabs.front().lgroup,
+                              &ctx->spec_tabs.front().e64})
             if (s->ptr) (void)hipFree(s->ptr);
         ctx->spec_tabs.erase(ctx->spec_tabs.begin());
     }
@@ -753,12 +796,17 @@ static int spectral_tables(f2_ctx* ctx, int C, int log2h, f2_spec_tables** out) 
     typedef std::complex<double> cd;
     std::vector<cd> w((size_t)M);
     std::vector<float> e((size_t)M * 2);
+    std::vector<double> e64((size_t)(log2h > 13 ? M : 0) * 2);   // float64 copy for k_spectrum_combine (decimated utterances)
     const long double tau = 2.0L * 3.14159265358979323846264338327950288L;
     for (int q = 0; q < M; ++q) {
         const long double ang = tau * (long double)q / (long double)M;
         w[(size_t)q] = cd((double)cosl(ang), (double)(-sinl(ang)));
         e[2 * (size_t)q] = (float)cosl(ang);
         e[2 * (size_t)q + 1] = (float)(-sinl(ang));
+        if (!e64.empty()) {
+            e64[2 * (size_t)q] = (double)cosl(ang);
+            e64[2 * (size_t)q + 1] = (double)(-sinl(ang));
+        }
     }
     std::vector<float> hu((size_t)C * t.tpitch * 4, 0.f);
     auto work = [&](int cbeg, int cend) {
@@ -790,6 +838,10 @@ static int spectral_tables(f2_ctx* ctx, int C, int log2h, f2_spec_tables** out) 
     F2_TRY(f2_reserve(ctx, t.hu, sizeof(float) * hu.size()));
     F2_TRY(f2_reserve(ctx, t.e, sizeof(float) * e.size()));
     F2_TRY(f2_reserve(ctx, t.lgroup, sizeof(int) * Lg.size()));
+    if (!e64.empty()) {
+        F2_TRY(f2_reserve(ctx, t.e64, sizeof(double) * e64.size()));
+        F2_HIP(ctx, hipMemcpyAsync(t.e64.ptr, e64.data(), sizeof(double) * e64.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
     F2_HIP(ctx, hipMemcpyAsync(t.hu.ptr, hu.data(), sizeof(float) * hu.size(), hipMemcpyHostToDevice, ctx->stream));
     F2_HIP(ctx, hipMemcpyAsync(t.e.ptr, e.data(), sizeof(float) * e.size(), hipMemcpyHostToDevice, ctx->stream));
     F2_HIP(ctx, hipMemcpyAsync(t.lgroup.ptr, Lg.data(), sizeof(int) * Lg.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -835,14 +887,27 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
     constexpr int H = 1 << LOG2H, M = 2 * H;
     f2_spec_tables* tab = nullptr;
     F2_TRY(spectral_tables(ctx, C, LOG2H, &tab));
-    F2_TRY(ensure_twiddles<double>(ctx, LOG2H, ctx->tw_sp[1][LOG2H]));
+    // float64 transform of the utterances: 2^13 packed complex points fit in LDS; longer rows are decimated in time
+    constexpr int LOGD = LOG2H > 13 ? LOG2H - 13 : 0, LOG2HS = LOG2H - LOGD;
+    F2_TRY(ensure_twiddles<double>(ctx, LOG2HS, ctx->tw_sp[1][LOG2HS]));
     F2_TRY(ensure_twiddles<float>(ctx, LOG2H, ctx->tw_sp[0][LOG2H]));
     const int64_t xpitch = H + 8;
     const int groups = (C + 63) / 64;
     F2_TRY(f2_prof_begin(ctx, F2_K_SPECTRUM));
-    hipLaunchKernelGGL((k_utterance_spectrum<WaveT, LOG2H>), dim3((unsigned)nutt), dim3(threads_for<double, LOG2H>()), 0, ctx->stream,
-                       d_wave, d_offsets, d_ulist, d_X, xpitch, (const cpx<double>*)ctx->tw_sp[1][LOG2H].ptr);
+    cpx<double>* d_part = nullptr;
+    if constexpr (LOGD > 0) {
+        F2_TRY(f2_reserve(ctx, ctx->spec_xpart, sizeof(double) * 2 * ((size_t)(1 << LOG2HS) + 1) * (size_t)nutt << LOGD));
+        d_part = (cpx<double>*)ctx->spec_xpart.ptr;
+    }
+    hipLaunchKernelGGL((k_utterance_spectrum<WaveT, LOG2HS, LOGD>), dim3((unsigned)nutt << LOGD), dim3(threads_for<double, LOG2HS>()),
+                       0, ctx->stream, d_wave, d_offsets, d_ulist, d_X, xpitch, d_part,
+                       (const cpx<double>*)ctx->tw_sp[1][LOG2HS].ptr);
     F2_HIP(ctx, hipGetLastError());
+    if constexpr (LOGD > 0) {
+        hipLaunchKernelGGL((k_spectrum_combine<LOG2HS, LOGD>), dim3((unsigned)((H + 256) / 256), (unsigned)nutt), dim3(256), 0,
+                           ctx->stream, (const cpx<double>*)d_part, (const cpx<double>*)tab->e64.ptr, d_X, xpitch);
+        F2_HIP(ctx, hipGetLastError());
+    }
     F2_TRY(f2_prof_end(ctx, F2_K_SPECTRUM));
     F2_TRY(f2_prof_begin(ctx, F2_K_TAIL));
     const int units = nutt * groups;
@@ -922,6 +987,7 @@ int f2_launch_spectral(f2_ctx* ctx, const void* d_wave, int wave_dtype, const in
     switch (log2h) {
         F2_SPEC_CASE(12)
         F2_SPEC_CASE(13)
+        F2_SPEC_CASE(14)
         default:
             return f2_fail(ctx, F2_ERR_UNSUPPORTED, "spectral path: length class 2^%d not built", log2h + 1);
     }

@@ -31,12 +31,13 @@ def fused(ctx, waves, coefs, lpf, cutoff=50.0, **opts):
 
 @pytest.mark.parametrize("lpf", [False, True])
 def test_ragged_batch_against_oracle_and_two_kernel_route(lpf):
-    """Lengths on both length classes the kernel serves (4097..8192, 8193..16384 samples), odd lengths, the shortest
-    padding it accepts (64 samples), and lengths it leaves to the two-kernel route (fewer padding samples, short and
-    long rows) in one batch; 128 channels."""
+    """Lengths on the three length classes the kernel serves (4097..8192, 8193..16384, 16385..32768 samples: the last one
+    transforms its utterances decimated by two), odd lengths, the shortest padding it accepts (64 samples), and lengths
+    it leaves to the two-kernel route (fewer padding samples, short and long rows) in one batch; 128 channels."""
     ctx = _lib.default_context()
     coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
-    lens = [16000, 15999, 9000, 8193, 16320, 16321, 4097, 5000, 8128, 8129, 300, 16384, 20000, 1]
+    lens = [16000, 15999, 9000, 8193, 16320, 16321, 4097, 5000, 8128, 8129, 300, 16384, 20000, 1, 32704, 32705, 16385,
+            27001, 40000]
     waves = [orc.synth_utterance(500 + i, n) for i, n in enumerate(lens)]
     got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
     old, _ = fused(ctx, waves, coefs, lpf, spectral=0)
