@@ -203,6 +203,7 @@ struct opt_entry {
 const opt_entry kOptions[] = {
     {"spectral", &f2_ctx::opt_spectral, nullptr, 0, 1},
     {"spectral_tol", nullptr, &f2_ctx::opt_spectral_tol, 0, 1},
+    {"spectral_min_rows", &f2_ctx::opt_spectral_min_rows, nullptr, 0, 1 << 30},
     {"k1_split", &f2_ctx::opt_k1_split, nullptr, -1, 64},
     {"k1_queue", &f2_ctx::opt_k1_queue, nullptr, -1, 1},
     {"k1_qwaves", &f2_ctx::opt_k1_qwaves, nullptr, 0, 1 << 20},
@@ -583,6 +584,9 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
             meta[(size_t)b] = 0;
             ++nspec;
         }
+        // a handful of rows cannot hide the serial run of k_tail_state (~0.1 ms for the low channels): small batches
+        // (one file of `cnn eval`, cfg1) keep the time-split filterbank kernel + envelope kernel
+        if ((int64_t)nspec * C < ctx->opt_spectral_min_rows) nspec = 0;
         if (nspec > 0) {
             size_t pos[F2_SPECTRAL_MAX_LOG2H + 1];
             for (int l = F2_SPECTRAL_MIN_LOG2H; l <= F2_SPECTRAL_MAX_LOG2H; ++l) {

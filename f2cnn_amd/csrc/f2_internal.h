@@ -76,6 +76,7 @@ struct f2_ctx {
     int spec_lptab_nt = 0;                // ... and workgroup size
     // options (f2_ctx_set_option); -1 = decide from the batch
     int opt_spectral = 1;                 // route eligible utterances of the fused call through the spectral kernel
+    int opt_spectral_min_rows = 4096;     // ... when the call has at least this many eligible rows (utterances x channels)
     float opt_spectral_tol = 4e-6f;       // accuracy guard: padding residual / row maximum that flags an utterance
     int opt_k1_split = -1;                // segments of the time-split filterbank (0 = never, >= 2 = force)
     int opt_k1_queue = -1;                // unit queue of the filterbank for ragged batches (0 / 1)

@@ -70,6 +70,8 @@ const char* f2_last_error(f2_ctx* ctx);
  * F2_ERR_INVALID. Keys (value -1 = decide from the batch, where stated):
  *   "spectral"       1 (default) / 0   f2_filterbank_envelope_fused serves eligible utterances with the one-kernel
  *                                      spectral path; 0 = always filterbank kernel + envelope kernel
+ *   "spectral_min_rows"  rows (utterances x channels) a call needs before that path is used (default 4096: below,
+ *                        the serial filter-state kernel is not hidden and the time-split filterbank kernel is faster)
  *   "spectral_tol"   accuracy guard of that path (default 4e-6): relative residual that sends an utterance back
  *   "k1_split"       -1 / 0 / K >= 2   time-split filterbank for small batches: auto / never / K segments
  *   "k1_queue"       -1 / 0 / 1        unit queue of the filterbank for ragged batches

@@ -17,8 +17,12 @@ LENGTH_POOL = [1, 2, 3, 5, 17, 63, 64, 65, 255, 257, 1000, 1023, 1025, 2049, 409
 
 @pytest.mark.parametrize("seed", range(40))
 def test_fused_random_ragged_batches(seed):
+    """(Half of the seeds let every eligible row - 4097..32768 samples, make_erb_filters table, float FFT, no GFB output -
+    take the one-kernel spectral route whatever the batch size - seeds 6, 9, 18, 21, 30, 33 have such rows, with and without
+    the low-pass; the others leave these small batches to the two-kernel route.)"""
     rng = np.random.default_rng(1000 + seed)
     ctx = _lib.default_context()
+    ctx.set_option("spectral_min_rows", 0 if seed % 4 in (1, 2) else 4096)
     Cn = int(rng.choice([1, 3, 7, 20, 64, 65, 70]))
     B = int(rng.integers(1, 7))
     lens = [int(rng.choice(LENGTH_POOL)) for _ in range(B)]
@@ -54,3 +58,4 @@ def test_fused_random_ragged_batches(seed):
         if want_gfb:
             got_gfb = gfb[Cn * off[b]:Cn * off[b + 1]].reshape(Cn, n)
             assert chan_relerr(got_gfb, ref_gfb) <= 1e-9, (seed, b, n)
+    ctx.set_option("spectral_min_rows", 4096)

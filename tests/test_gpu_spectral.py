@@ -22,6 +22,7 @@ def fused(ctx, waves, coefs, lpf, cutoff=50.0, **opts):
     flat = np.concatenate(waves)
     dtype = _lib.WAVE_I16 if flat.dtype == np.int16 else _lib.WAVE_F64
     env = np.full(C * int(offs[-1]), np.nan)
+    opts.setdefault("spectral_min_rows", 0)      # (small test batches: route by eligibility alone)
     with ctx.options(**opts):
         ctx.filterbank_envelope_fused(flat, dtype, offs, coefs, len(waves), C, lpf, cutoff, _lib.FFT_F32, env, None,
                                       _lib.MEM_HOST)
@@ -98,3 +99,20 @@ def test_accuracy_guard_sends_a_late_click_back():
     got, flagged = fused(ctx, waves, coefs, False, spectral=1, spectral_tol=1.0)
     assert flagged == 0
     assert chan_relerr(got[1], orc.filter_and_envelope(click, coefs, False, 0)) > TOL
+
+
+def test_small_batches_keep_the_two_kernel_route():
+    """Below `spectral_min_rows` eligible rows the call does not use the spectral kernel (its serial filter-state kernel
+    would dominate one file's latency); same results either way."""
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 64, 100))
+    w = [orc.synth_utterance(1234, 16000)]
+    ctx.prof_enable(True)
+    a, _ = fused(ctx, w, coefs, True, spectral=1, spectral_min_rows=4096)
+    small = set(ctx.prof_get())
+    ctx.prof_enable(True)
+    b, _ = fused(ctx, w, coefs, True, spectral=1, spectral_min_rows=0)
+    forced = set(ctx.prof_get())
+    ctx.prof_enable(False)
+    assert "k_spectral_envelope" not in small and "k_spectral_envelope" in forced
+    assert chan_relerr(a[0], b[0]) <= 4e-6 and chan_relerr(a[0], orc.filter_and_envelope(w[0], coefs, True, 50)) <= TOL
