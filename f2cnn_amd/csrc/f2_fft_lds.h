@@ -8,6 +8,13 @@
 
 namespace f2fft {
 
+// knock-out (timing only, results wrong): -DF2_KO_BARRIER turns the workgroup barriers of the transforms into nothing
+#ifdef F2_KO_BARRIER
+#define F2_FFT_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define F2_FFT_BARRIER() __syncthreads()
+#endif
+
 #ifndef F2_PLAN13_PASSES
 #define F2_PLAN13_PASSES 4
 #endif
@@ -111,7 +118,12 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
     static_assert(ITER * R <= PTV, "register array too small");
     constexpr bool FULL = NB % NT == 0;   // every thread owns ITER whole butterflies: no guards
     const cpx<F>* __restrict__ twp = tw + plan_tw_offset(LOG2H, PASS);
-    if constexpr (!SRC_REGS) {
+#ifdef F2_KO_X12   // knock-out (timing only): no LDS exchange between passes 1 and 2
+    constexpr bool KO_READ = PASS == 2, KO_WRITE = PASS == 1;
+#else
+    constexpr bool KO_READ = false, KO_WRITE = false;
+#endif
+    if constexpr (!SRC_REGS && !KO_READ) {
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
             const int bf = tid + i * NT;
@@ -147,7 +159,7 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
                 }
             }
         }
-        __syncthreads();
+        F2_FFT_BARRIER();
     }
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
@@ -194,7 +206,7 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
 #ifdef F2_KO_LDS
             if constexpr (false) {
 #else
-            if constexpr (!DST_REGS) {
+            if constexpr (!DST_REGS && !KO_WRITE) {
 #endif
                 const int q = bf & (S - 1);
                 const int base = q + (bf - q) * R;
@@ -209,7 +221,7 @@ __device__ __forceinline__ void fft_pass(cpx<F>* lds, const cpx<F>* __restrict__
             }
         }
     }
-    if constexpr (!DST_REGS) __syncthreads();
+    if constexpr (!DST_REGS && !KO_WRITE) F2_FFT_BARRIER();
 }
 
 template <typename F, int LOG2H, bool INVERSE, int PTV, int NT, bool T0REGS = false, int PASS = 0>

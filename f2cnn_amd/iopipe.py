@@ -43,14 +43,37 @@ class JobReport:
         self.audio_s = 0.0
         self._lock = threading.Lock()
 
-    def pending(self, items, outputs_of):
-        """The items still to do: all of them, or with skip_existing those with a missing or stale output."""
+    def pending(self, items, outputs_of, params=None, stamp_dir=None):
+        """The items still to do: all of them, or with skip_existing those with a missing, stale or incomplete output
+        (an .npy whose header promises more bytes than the file holds - what a killed run leaves behind if it did not
+        write through save_npy_atomic - counts as missing).
+
+        params / stamp_dir: the settings the outputs depend on (low-pass on / cutoff, ...) are written to
+        `<stamp_dir>/.f2cnn_<command>.rank<r>.json` when the run starts; a resume whose settings differ from the
+        stamp it finds recomputes everything instead of keeping outputs made with the other settings."""
+        stamp = None
+        if params is not None and stamp_dir is not None:
+            stamp = os.path.join(stamp_dir, ".f2cnn_{}.rank{}.json".format(self.command.replace(" ", "_"), self.rank))
+            previous = None
+            try:
+                with open(stamp) as f:
+                    previous = _json.load(f)
+            except (OSError, ValueError):
+                pass
+            try:
+                with open(stamp, "w") as f:
+                    _json.dump(params, f)
+            except OSError:
+                pass
+            if self.skip_existing and previous is not None and previous != params:
+                print("Settings changed since the outputs were written ({} -> {}): nothing is skipped.".format(previous, params))
+                return list(items)
         if not self.skip_existing:
             return list(items)
         todo = []
         for it in items:
             outs = outputs_of(it)
-            fresh = all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(it) for o in outs)
+            fresh = all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(it) and npy_complete(o) for o in outs)
             if fresh:
                 self.skipped += 1
             else:
@@ -176,31 +199,40 @@ class ArrayPool:
 
     def __init__(self, keep=6, alloc=None):
         self._buffers = []          # [buffer, nbytes, busy]
-        self._lock = threading.Lock()
+        # re-entrant: a lease's finalizer (-> _release) may run inside empty() when a garbage collection starts there
+        self._lock = threading.RLock()
         self._alloc = alloc or (lambda nbytes: numpy.empty(nbytes, numpy.uint8))
+        self._retired = []          # buffers dropped from the pool, freed by the thread that calls empty()
         self.keep = keep
 
     def _release(self, entry):
+        # may run on a writer thread or inside a collection: only bookkeeping here. A buffer that leaves the pool is
+        # parked in _retired and dropped by the next empty() call - i.e. on the driver's thread, which owns the device
+        # context the page-locked buffers were allocated from (a context is not thread-safe)
         with self._lock:
             entry[2] = False
             idle = [e for e in self._buffers if not e[2]]
             if len(self._buffers) > self.keep and len(idle) > 1:   # drop the smallest buffer nobody uses
                 victim = min(idle, key=lambda e: e[1])
                 self._buffers = [e for e in self._buffers if e is not victim]
+                self._retired.append(victim[0])
 
     def empty(self, count, dtype=numpy.float64):
         """Uninitialised 1-D array of `count` elements backed by a pooled buffer."""
         dtype = numpy.dtype(dtype)
         nbytes = int(count) * dtype.itemsize
         with self._lock:
+            retired, self._retired = self._retired, []
             fits = [e for e in self._buffers if not e[2] and e[1] >= nbytes]
-            if fits:
-                entry = min(fits, key=lambda e: e[1])
-            else:
-                size = max(nbytes + nbytes // 8, 1 << 20)
-                entry = [self._alloc(size), size, False]
+            entry = min(fits, key=lambda e: e[1]) if fits else None
+            if entry is not None:
+                entry[2] = True
+        del retired                  # (frees page-locked memory here, outside the lock, on the calling thread)
+        if entry is None:
+            size = max(nbytes + nbytes // 8, 1 << 20)
+            entry = [self._alloc(size), size, True]     # allocated outside the lock
+            with self._lock:
                 self._buffers.append(entry)
-            entry[2] = True
         arr = numpy.frombuffer(memoryview(entry[0]).cast("B")[:nbytes], dtype=dtype)
         weakref.finalize(arr, self._release, entry)
         return arr
@@ -214,6 +246,40 @@ def _pinned(nbytes):
 
 
 host_pool = ArrayPool(keep=16, alloc=_pinned)
+
+
+def save_npy_atomic(filename, array):
+    """numpy.save(filename, array) that never leaves a partial file under the final name: the array goes to
+    `<name>.tmp.<pid>` in the same directory and is renamed over the target (os.replace) once it is complete, so
+    `--skip-existing` can trust every file it finds. `filename` gets the `.npy` suffix numpy.save would add."""
+    final = filename if str(filename).endswith(".npy") else str(filename) + ".npy"
+    tmp = "{}.tmp.{}".format(final, os.getpid())
+    try:
+        with open(tmp, "wb") as f:
+            numpy.save(f, array)
+        os.replace(tmp, final)
+    except BaseException:
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+        raise
+    return final
+
+
+def npy_complete(path):
+    """True unless `path` is an .npy file whose header describes more payload than the file contains."""
+    if not str(path).endswith(".npy"):
+        return True
+    try:
+        with open(path, "rb") as f:
+            version = numpy.lib.format.read_magic(f)
+            reader = numpy.lib.format.read_array_header_1_0 if version == (1, 0) else numpy.lib.format.read_array_header_2_0
+            shape, _, dtype = reader(f)
+            need = f.tell() + int(numpy.prod(shape, dtype=numpy.int64)) * dtype.itemsize
+        return os.path.getsize(path) >= need
+    except (OSError, ValueError):
+        return False
 
 
 def npy_layout(path):

@@ -13,7 +13,7 @@ import numpy
 
 from ... import _lib
 from ...config import F2Config
-from ...iopipe import JobReport, Unreadable, host_pool, npy_layout, read_npy_into, run_batches
+from ...iopipe import JobReport, Unreadable, host_pool, npy_layout, read_npy_into, run_batches, save_npy_atomic
 from ...runtime import shard_for_rank
 
 FFT_PRECISION = _lib.FFT_F64 if os.environ.get("F2CNN_FFT", "f32").lower() in ("f64", "double") else _lib.FFT_F32
@@ -66,7 +66,7 @@ def envelope_filename(gfbFileName):
 
 
 def SaveEnvelope(matrix, gfbFileName, nbf=None, done=None):
-    numpy.save(envelope_filename(gfbFileName), matrix)
+    save_npy_atomic(envelope_filename(gfbFileName), matrix)
     if nbf is not None:
         print("\t{:<50} done ! {}/{} Files.".format(envelope_filename(gfbFileName), done, nbf))
 
@@ -91,7 +91,9 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16, skip_existing=Fal
     else:
         print("Not using Low Pass Filtering")
     print(len(gfbFiles), ".GFB.npy files found")
-    mine = report.pending(shard_for_rank(gfbFiles), lambda name: [envelope_filename(name) + '.npy'])
+    mine = report.pending(shard_for_rank(gfbFiles), lambda name: [envelope_filename(name) + '.npy'],
+                          params={"lpf": bool(LPF), "cutoff": CUTOFF if LPF else None, "fft": int(FFT_PRECISION)},
+                          stamp_dir=os.path.join('resources', 'f2cnn'))
 
     contexts = _lib.pipeline_contexts(2)     # alternate streams: one batch's copies beside the next one's kernels
     turn = [0]
@@ -152,7 +154,7 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16, skip_existing=Fal
         return finish
 
     def save(name, e):
-        numpy.save(envelope_filename(name), e)
+        save_npy_atomic(envelope_filename(name), e)
         print("\t{:<50} done ! {}/{} Files.".format(envelope_filename(name), report.add(e.shape[1], framerate), len(mine)))
 
     run_batches(mine, report.guard(load), compute, save, batch=batch_files, plan=plan)
@@ -188,7 +190,9 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True, sk
     def outputs(name):
         base = os.path.splitext(name)[0]
         return [base + '.ENV' + str(METHOD) + '.npy'] + ([base + '.GFB.npy'] if keep_gfb else [])
-    mine = report.pending(shard_for_rank(wavFiles), outputs)
+    mine = report.pending(shard_for_rank(wavFiles), outputs,
+                          params={"lpf": bool(LPF), "cutoff": CUTOFF if LPF else None, "fft": int(FFT_PRECISION)},
+                          stamp_dir=os.path.join('resources', 'f2cnn'))
     rates = {}
 
     def load(name):
@@ -223,8 +227,8 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True, sk
         env, gfb = res
         base = os.path.splitext(name)[0]
         if gfb is not None:
-            numpy.save(base + '.GFB', gfb)
-        numpy.save(base + '.ENV' + str(METHOD), env)
+            save_npy_atomic(base + '.GFB', gfb)
+        save_npy_atomic(base + '.ENV' + str(METHOD), env)
         print("\t{:<50} done ! {}/{} Files.".format(base + '.ENV' + str(METHOD), report.add(env.shape[1], rates[name]),
                                                      len(mine)))
 

@@ -98,25 +98,50 @@ def GenerateInputData(labelFile=None, inputFile=None, LPF=False, CUTOFF=100):
     print('')
 
 
+def _run_token():
+    """What tells this launch's marker files from those a dead earlier launch left behind: the launcher's run id
+    ($F2CNN_RUN_ID, torchrun's $TORCHELASTIC_RUN_ID, else $MASTER_PORT). Ranks started by hand without any of them
+    share the token "0": export F2CNN_RUN_ID then."""
+    for key in ("F2CNN_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
+        v = os.environ.get(key)
+        if v:
+            return "".join(ch if ch.isalnum() else "_" for ch in v)
+    return "0"
+
+
 def _marker(target, what, rank):
-    return "{}.{}.rank{}".format(target, what, rank)
+    return "{}.{}.{}.rank{}".format(target, what, _run_token(), rank)
 
 
 def _shared_output(target, shape, rank, world, timeout=600.0):
-    """The pre-sized output .npy all ranks write into (numpy.lib.format.open_memmap). Rank 0 creates it and announces
-    it; the others wait for the announcement (the ranks of a file command share nothing but the file system)."""
+    """The pre-sized output .npy all ranks write into (numpy.lib.format.open_memmap). Rank 0 creates it - under a
+    temporary name, renamed into place once its header is written - and announces it with a marker that carries this
+    launch's token and the shape; the others wait for exactly that marker (the ranks of a file command share nothing
+    but the file system). Every rank removes only its OWN markers of an earlier launch with the same token."""
+    for what in ("ready", "done"):
+        if os.path.exists(_marker(target, what, rank)):
+            os.remove(_marker(target, what, rank))
     if rank == 0:
-        for r in range(world):
-            for what in ("ready", "done"):
-                if os.path.exists(_marker(target, what, r)):
-                    os.remove(_marker(target, what, r))
-        out = numpy.lib.format.open_memmap(target, mode='w+', dtype=numpy.float32, shape=shape)
-        open(_marker(target, "ready", 0), "w").close()
+        tmp = "{}.tmp.{}".format(target, os.getpid())
+        out = numpy.lib.format.open_memmap(tmp, mode='w+', dtype=numpy.float32, shape=shape)
+        del out
+        os.replace(tmp, target)
+        out = numpy.lib.format.open_memmap(target, mode='r+')
+        with open(_marker(target, "ready", 0), "w") as f:
+            f.write(repr(tuple(shape)))
         return out
     deadline = time.time() + timeout
-    while not os.path.exists(_marker(target, "ready", 0)):
+    started = time.time()
+    while True:
+        mk = _marker(target, "ready", 0)
+        try:
+            # a marker of this token that predates this rank by more than a day is a leftover, not an announcement
+            if os.path.getmtime(mk) >= started - 86400 and open(mk).read() == repr(tuple(shape)):
+                break
+        except OSError:
+            pass
         if time.time() > deadline:
-            raise TimeoutError("rank 0 did not create {}".format(target))
+            raise TimeoutError("rank 0 did not create {} (token {})".format(target, _run_token()))
         time.sleep(0.05)
     out = numpy.lib.format.open_memmap(target, mode='r+')
     if out.shape != shape or out.dtype != numpy.float32:

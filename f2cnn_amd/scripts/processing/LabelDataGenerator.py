@@ -91,8 +91,10 @@ def ExtractLabel(wavFile, config):
     region, speaker, sentence = os.path.basename(base).split(".")
     subset = os.path.basename(os.path.dirname(base))
     keep = p < risk
-    rows = [[subset, region, speaker, sentence, str(ph), int(t), a, pv, 1 if a > 0 else 0]
-            for ph, t, a, pv in zip(names[keep], steps[keep], numpy.round(slope[keep], 5), numpy.round(p[keep], 5))]
+    # (the sign column follows the slope as fitted, not its 5-decimal rounding: reference :70-75)
+    rows = [[subset, region, speaker, sentence, str(ph), int(t), a, pv, 1 if a_raw > 0 else 0]
+            for ph, t, a, pv, a_raw in zip(names[keep], steps[keep], numpy.round(slope[keep], 5), numpy.round(p[keep], 5),
+                                           slope[keep])]
     return rows or None
 
 

@@ -310,8 +310,9 @@ def test_job_report_resume_failures_and_metrics(tmp_path, monkeypatch):
         p = tmp_path / f"in{i}.WAV"
         p.write_bytes(b"x")
         srcs.append(str(p))
-    (tmp_path / "in0.GFB.npy").write_bytes(b"y")                       # fresh output: skipped
-    (tmp_path / "in1.GFB.npy").write_bytes(b"y")
+    import numpy as np
+    np.save(tmp_path / "in0.GFB.npy", np.zeros((2, 3)))               # fresh, complete output: skipped
+    np.save(tmp_path / "in1.GFB.npy", np.zeros((2, 3)))
     os.utime(tmp_path / "in1.GFB.npy", (time.time() - 100, time.time() - 100))   # older than its input: redone
     outs = lambda name: [os.path.splitext(name)[0] + ".GFB.npy"]
     rep = JobReport("prepare filter", skip_existing=True, metrics=str(tmp_path / "m.json"))
@@ -331,3 +332,37 @@ def test_job_report_resume_failures_and_metrics(tmp_path, monkeypatch):
     assert json.load(open(tmp_path / "m.json"))["failed"][0][0].endswith("in2.WAV")
     args = cli.build_parser().parse_args(["prepare", "features", "--skip-existing", "--metrics", "m.json", "-c", "50"])
     assert args.skip_existing and args.metrics == "m.json" and args.CUTOFF == 50
+
+
+def test_atomic_npy_save_and_resume_check(tmp_path):
+    """The file drivers' writers never leave a partial file under the final name, and the resume logic recognises one
+    (a killed `numpy.save` used to be skipped for good by --skip-existing)."""
+    import numpy as np
+    from f2cnn_amd import iopipe
+    a = np.arange(12, dtype=np.float64).reshape(3, 4)
+    out = iopipe.save_npy_atomic(str(tmp_path / "x.GFB"), a)
+    assert out.endswith("x.GFB.npy") and np.array_equal(np.load(out), a)
+    assert [f.name for f in tmp_path.iterdir()] == ["x.GFB.npy"]
+    assert iopipe.npy_complete(out)
+    raw = open(out, "rb").read()
+    open(out, "wb").write(raw[:-8])
+    assert not iopipe.npy_complete(out)
+    open(out, "wb").write(b"not an npy file")
+    assert not iopipe.npy_complete(out)
+
+    class Unsavable:            # numpy.save raises half way: nothing appears under the final name, no temp file stays
+        def __array__(self, *a, **k):
+            raise RuntimeError("boom")
+    import pytest
+    with pytest.raises(Exception):
+        iopipe.save_npy_atomic(str(tmp_path / "y"), Unsavable())
+    assert sorted(f.name for f in tmp_path.iterdir()) == ["x.GFB.npy"]
+    # JobReport.pending: stale settings disable the skipping
+    rep = iopipe.JobReport("prepare envelope", skip_existing=True)
+    src = tmp_path / "in.GFB.npy"
+    np.save(src, a)
+    iopipe.save_npy_atomic(str(tmp_path / "in.ENV1"), a)
+    outs = lambda name: [str(tmp_path / "in.ENV1.npy")]
+    assert rep.pending([str(src)], outs, params={"cutoff": 50}, stamp_dir=str(tmp_path)) == []
+    rep2 = iopipe.JobReport("prepare envelope", skip_existing=True)
+    assert rep2.pending([str(src)], outs, params={"cutoff": 100}, stamp_dir=str(tmp_path)) == [str(src)]

@@ -1,3 +1,4 @@
+import os
 """CPU-only tests of the host-side mirror (filter design etc.) against the golden vectors."""
 import numpy as np
 import pytest
@@ -19,3 +20,67 @@ def test_filter_design_matches_reference(golden, C):
 def test_erb_space_defaults():
     assert filters.erb_space().shape == (100,)
     assert abs(filters.erb_point(100, 8000, 1) - 100) < 1e-9 and abs(filters.erb_point(100, 8000, 0) - 8000) < 1e-9
+
+
+def test_rank_placement_from_a_sysfs_tree(tmp_path, monkeypatch):
+    """pin_to_gpu_numa_node reads the GPU -> NUMA node -> cpulist chain from sysfs (here: a fabricated two-socket tree
+    with four GPUs, a network card and a GPU without a node) and never touches the device."""
+    import os
+    from f2cnn_amd import runtime
+
+    def dev(bdf, vendor, cls, node):
+        d = tmp_path / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "class").write_text(cls + "\n")
+        if node is not None:
+            (d / "numa_node").write_text(str(node) + "\n")
+    dev("0000:05:00.0", "0x1002", "0x120000", 0)
+    dev("0000:15:00.0", "0x1002", "0x120000", 0)
+    dev("0000:85:00.0", "0x1002", "0x120000", 1)
+    dev("0000:95:00.0", "0x1002", "0x038000", None)
+    dev("0000:01:00.0", "0x15b3", "0x020000", 0)          # not a GPU
+    have = sorted(os.sched_getaffinity(0))
+    half = max(1, len(have) // 2)
+    for node, cpus in ((0, have[:half]), (1, have[half:] or have[:1])):
+        d = tmp_path / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert [n for _, n in runtime.gpu_numa_nodes(str(tmp_path))] == [0, 0, 1, -1]
+    got = runtime.pin_to_gpu_numa_node(2, sysfs=str(tmp_path), apply=False)
+    assert got == {"gpu": "0000:85:00.0", "numa_node": 1, "cpus": len(have[half:] or have[:1])}
+    assert runtime.pin_to_gpu_numa_node(3, sysfs=str(tmp_path), apply=False) is None        # no node reported
+    assert runtime.pin_to_gpu_numa_node(7, sysfs=str(tmp_path), apply=False) is None        # no such GPU
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert runtime.pin_to_gpu_numa_node(0, sysfs=str(tmp_path), apply=False)["numa_node"] == 1
+    assert runtime.pin_to_gpu_numa_node(1, sysfs=str(tmp_path), apply=False)["numa_node"] == 0
+    assert runtime._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert sorted(os.sched_getaffinity(0)) == have                                          # apply=False changed nothing
+
+
+def test_shared_output_markers_carry_the_launch_token(tmp_path, monkeypatch):
+    """`prepare input` with several ranks: the marker files are named after the launch (a dead run's
+    `ready` marker must not send a rank into the old output file)."""
+    import numpy as np
+    from f2cnn_amd.scripts.processing import InputGenerator as ig
+    target = str(tmp_path / "input_data.npy")
+    monkeypatch.setenv("F2CNN_RUN_ID", "old/run")
+    old = ig._shared_output(target, (2, 11, 4), 0, 2)
+    old[:] = 7
+    del old
+    assert os.path.exists(ig._marker(target, "ready", 0)) and "old_run" in ig._marker(target, "ready", 0)
+    monkeypatch.setenv("F2CNN_RUN_ID", "new-run")
+    # rank 1 of the new launch is not fooled by the old marker: it times out until rank 0 of ITS launch announces the file
+    import pytest
+    with pytest.raises(TimeoutError):
+        ig._shared_output(target, (3, 11, 4), 1, 2, timeout=0.3)
+    new = ig._shared_output(target, (3, 11, 4), 0, 2)
+    assert new.shape == (3, 11, 4)
+    mine = ig._shared_output(target, (3, 11, 4), 1, 2, timeout=5.0)
+    mine[1] = 1.0
+    mine.flush()
+    assert np.load(target).shape == (3, 11, 4) and np.load(target)[1].min() == 1.0
+    with pytest.raises(TimeoutError):          # a marker with another shape is not this launch's announcement either
+        ig._shared_output(target, (4, 11, 4), 1, 2, timeout=0.3)

@@ -19,7 +19,8 @@ def test_bound_sheet_runs_on_the_committed_files():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bound_sheet.py"), pmc, line, traffic],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    assert "K1 k_erb_filterbank" in out.stdout and "K2 k_envelope" in out.stdout and "of 8 TB/s" in out.stdout
+    assert "of 8 TB/s" in out.stdout
+    assert ("KS k_spectral_envelope" in out.stdout) or ("K1 k_erb_filterbank" in out.stdout and "K2 k_envelope" in out.stdout)
 
 
 def test_default_line_keeps_the_contract_fields():
@@ -32,4 +33,4 @@ def test_default_line_keeps_the_contract_fields():
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]   # measured bytes never below the required ones
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     t = json.load(open(newest("r*_traffic_cfg3.json")))
-    assert t["k_envelope"]["hbm_bytes_per_launch"] == r["traffic"] or r["traffic"] is None
+    assert r["traffic"] is None or t[r["kernel"]]["hbm_bytes_per_launch"] == r["traffic"]

@@ -22,10 +22,17 @@ C, N = 128, 16000
 out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc.sh) on `bench.py --workload cfg3 "
                  "--steps 2 --warmup 1 --no-cpu-baseline`; counters are KiB per dispatch, mean over the dispatches seen. "
                  "gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-byte requests of wide streaming reads "
-                 "at 64 bytes, so it is doubled; WRITE_SIZE is exact.",
+                 "at 64 bytes, so it is doubled; WRITE_SIZE is exact. The reads of k_spectral_envelope are its channel tables and "
+                 "utterance spectra missing the XCD's L2 (served by the Infinity Cache, which these counters include): cache "
+                 "traffic of 17 MB of tables + 64 MB of spectra, not algorithmic bytes.",
        "workload": "cfg3", "batch": B, "lib_source_hash": bench.lib_source_hash()}
-names = {"k_erb_filterbank": "k_erb_filterbank", "k_envelope<float, 13>": "k_envelope"}
-need = {"k_erb_filterbank": B * 2 * N, "k_envelope": B * 8 * C * N}
+names = {"k_erb_filterbank": "k_erb_filterbank", "k_envelope<float, 13>": "k_envelope",
+         "k_spectral_envelope<13>": "k_spectral_envelope", "k_utterance_spectrum": "k_utterance_spectrum", "k_tail_state": "k_tail_state"}
+# bytes each kernel MUST move: the spectral kernel writes the envelopes, its pre-kernels read the waves once each;
+# when the spectral route serves the whole batch the two-kernel launches only skip utterances (nothing required of them)
+spectral = any("k_spectral_envelope" in k for k in fetch)
+need = {"k_erb_filterbank": 0 if spectral else B * 2 * N, "k_envelope": 0 if spectral else B * 8 * C * N,
+        "k_spectral_envelope": B * 8 * C * N, "k_utterance_spectrum": B * 2 * N, "k_tail_state": 0}
 for pat, key in names.items():
     kf = [k for k in fetch if pat in k]
     kw = [k for k in write if pat in k]
