@@ -433,6 +433,7 @@ int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C) {
     F2_HIP(ctx, hipMemcpyAsync(ctx->coefs.ptr, coefs, sizeof(double) * 10 * (size_t)C, hipMemcpyHostToDevice, ctx->stream));
     F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->coefs_host.assign(coefs, coefs + (size_t)C * 10);
+    ctx->spec_coefs_ok = -1;      // eligibility of this table for the spectral kernel: decided on first use
     return F2_OK;
 }
 
@@ -573,7 +574,9 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
     // through the filterbank kernel + envelope kernel below, which skip utterances whose flag is 0.
     const int* d_uflag = nullptr;
     ctx->spec_last_B = 0;
-    if (ctx->opt_spectral && fft_precision == F2_FFT_F32 && !d_gfb && f2_spectral_supports_coefs(ctx->coefs_host, C, nullptr)) {
+    if (ctx->opt_spectral && fft_precision == F2_FFT_F32 && !d_gfb && ctx->spec_coefs_ok < 0)
+        ctx->spec_coefs_ok = f2_spectral_supports_coefs(ctx->coefs_host, C, nullptr) ? 1 : 0;   // (once per table: ~50 us of logarithms)
+    if (ctx->opt_spectral && fft_precision == F2_FFT_F32 && !d_gfb && ctx->spec_coefs_ok == 1) {
         std::vector<int> meta((size_t)B, 1);
         std::vector<int> lists[F2_SPECTRAL_MAX_LOG2H + 1];
         int nspec = 0;

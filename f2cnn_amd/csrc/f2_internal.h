@@ -69,6 +69,7 @@ struct f2_ctx {
     f2_scratch spec_xpart;                // float64 partial spectra of decimated (long) utterances
     f2_scratch spec_meta, spec_uflag;     // [initial flags (B) | utterance lists]; the flags the kernels update
     std::vector<int> spec_meta_host;      // what spec_meta currently holds
+    int spec_coefs_ok = -1;               // coefs_host eligible for the spectral kernel: -1 not decided, 0, 1
     size_t spec_last_B = 0;               // batch size of the last fused call that used the spectral kernel (0: none)
     f2_scratch tw_sp[2][16];              // its twiddle tables, [precision][log2 H]
     f2_scratch spec_lptab;                // low-pass powers per thread (lowpass_pairs_store_tab) ...
