@@ -1,0 +1,102 @@
+// Merged passes 1 + 2 of the 8192-point transform (see the comment below); included by f2_spectral.hip inside its
+// anonymous namespace, after f2_fft_lds.h.
+#pragma once
+// ---- passes 1 and 2 of the 16-8-4-16 plan (H = 8192, 512 threads) in ONE trip through LDS ----
+// Pass 2 (radix 4, stride 128) combines four outputs of pass 1 (radix 8, stride 16) that belong to butterflies
+// b = q + 16 p, p = p_lo + 16 p_hi, differing in p_hi only. With pass 1's butterflies dealt so that p_hi = i + 2 (lane >> 5)
+// (i = the thread's first / second butterfly) those four values sit in one lane pair (l, l + 32): eight
+// v_permlane32_swap per butterfly pair give every lane all four inputs of four radix-4 butterflies (the low lane those
+// of pass-1 outputs k = 0..3, the high lane k = 4..7), and the exchange pass 1 -> pass 2 (16 ds_write_b64 + 16 ds_read_b64
+// per thread, two barriers) is gone. Same arithmetic, same twiddle tables, same result bits as fft_pass<1> + fft_pass<2>.
+// Measured bound (a build that simply skips that exchange, results wrong): -5 % on the kernel.
+template <int NT, int PTV>
+__device__ __forceinline__ void fft13_pass12_merged(cpx<float>* lds, const cpx<float>* twl, int tid, cpx<float> (&v)[PTV]) {
+    constexpr int LOG2H = 13;
+    static_assert(NT == 512 && PTV >= 16 && plan_npass(LOG2H) == 4 && plan_bits(LOG2H, 1) == 3 && plan_bits(LOG2H, 2) == 2 &&
+                      plan_bits(LOG2H, 0) == 4, "the 16-8-4-16 plan on 512 threads");
+    constexpr int OFF2 = plan_tw_offset(LOG2H, 2) - plan_tw_offset(LOG2H, 1);   // pass 2's table inside twl
+    const int l = tid & 63, hl = l >> 5;
+    const int base8 = (l & 31) + 32 * (tid >> 6);        // q + 16 p_lo
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int b = base8 + 256 * (i + 2 * hl);
+        const cpx<float>* src = lds + cpad(b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i * 8 + j] = src[j * (1024 + 64)];   // cpad(b + 1024 j)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        dft<8>(&v[i * 8]);                                  // X[k] in v[8 i + brev<8>(k)]
+        const cpx<float>* t1 = twl + (((base8 >> 4) + 16 * (i + 2 * hl)));   // p = b >> 4
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[i * 8 + brev<8>(k)] = cmul(v[i * 8 + brev<8>(k)], t1[(k - 1) * 64]);
+    }
+    // lane pair exchange: A = (i, k), B = (i, k + 4), k < 4. Afterwards, in both lanes, A holds the value of p_hi = i and
+    // B that of p_hi = i + 2 for the pass-1 output kk = k + 4 (lane >> 5)
+    // (inline asm: this compiler mis-tracks the two results of __builtin_amdgcn_permlane32_swap once they are written
+    // back over their inputs - it went on to read one register for both; the instruction updates both operands in
+    // place, which "+v" states exactly. s_nop: no hazard handling inside an asm block.)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        cpx<float>& A0 = v[i * 8 + brev<8>(0)];
+        cpx<float>& B0 = v[i * 8 + brev<8>(4)];
+        cpx<float>& A1 = v[i * 8 + brev<8>(1)];
+        cpx<float>& B1 = v[i * 8 + brev<8>(5)];
+        cpx<float>& A2 = v[i * 8 + brev<8>(2)];
+        cpx<float>& B2 = v[i * 8 + brev<8>(6)];
+        cpx<float>& A3 = v[i * 8 + brev<8>(3)];
+        cpx<float>& B3 = v[i * 8 + brev<8>(7)];
+#ifdef F2_MERGE_SHFL   // diagnostic: the same exchange through ds_bpermute
+        auto xchg = [&](cpx<float>& A, cpx<float>& B) {
+            const cpx<float> pa = {__shfl_xor(A.re, 32), __shfl_xor(A.im, 32)}, pb = {__shfl_xor(B.re, 32), __shfl_xor(B.im, 32)};
+            const cpx<float> a2 = hl ? pb : A, b2 = hl ? B : pa;
+            A = a2;
+            B = b2;
+        };
+        xchg(A0, B0);
+        xchg(A1, B1);
+        xchg(A2, B2);
+        xchg(A3, B3);
+#else
+        asm volatile("s_nop 1\n\t"
+                     "v_permlane32_swap_b32 %0, %1\n\t"
+                     "v_permlane32_swap_b32 %2, %3\n\t"
+                     "v_permlane32_swap_b32 %4, %5\n\t"
+                     "v_permlane32_swap_b32 %6, %7\n\t"
+                     "v_permlane32_swap_b32 %8, %9\n\t"
+                     "v_permlane32_swap_b32 %10, %11\n\t"
+                     "v_permlane32_swap_b32 %12, %13\n\t"
+                     "v_permlane32_swap_b32 %14, %15\n\t"
+                     "s_nop 1"
+                     : "+v"(A0.re), "+v"(B0.re), "+v"(A0.im), "+v"(B0.im), "+v"(A1.re), "+v"(B1.re), "+v"(A1.im), "+v"(B1.im),
+                       "+v"(A2.re), "+v"(B2.re), "+v"(A2.im), "+v"(B2.im), "+v"(A3.re), "+v"(B3.re), "+v"(A3.im), "+v"(B3.im));
+#endif
+    }
+    const int q = base8 & 15, plo = base8 >> 4;
+    const cpx<float>* t2 = twl + OFF2 + plo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cpx<float> t[4] = {v[brev<8>(k)], v[8 + brev<8>(k)], v[brev<8>(k + 4)], v[8 + brev<8>(k + 4)]};   // p_hi = 0..3
+        dft<4>(t);                                          // X[k2] in t[brev<4>(k2)]
+        const int pos = q + 16 * (k + 4 * hl) + 512 * plo;
+        lds[cpad(pos)] = t[0];
+#pragma unroll
+        for (int k2 = 1; k2 < 4; ++k2) lds[cpad(pos + 128 * k2)] = cmul(t[brev<4>(k2)], t2[(k2 - 1) * 16]);
+    }
+    __syncthreads();
+}
+
+// the whole 8192-point transform, registers (first-pass layout) to registers (as fft_regs_to_regs leaves them)
+template <int PTV, int NT, bool T0REGS>
+__device__ __forceinline__ void fft13_regs_to_regs(cpx<float>* lds, const cpx<float>* __restrict__ tw, const cpx<float>* twl, int tid,
+                                                   cpx<float> (&v)[PTV]) {
+#ifdef F2_KS_PLAIN_PASSES   // diagnostic: the four separate passes of f2_fft_lds.h
+    fft_regs_to_regs<float, 13, PTV, NT, T0REGS>(lds, tw, twl, tid, v);
+#else
+    fft_pass<float, 13, 0, true, false, PTV, NT, false, T0REGS>(lds, tw, twl, tid, v);
+    fft13_pass12_merged<NT, PTV>(lds, twl, tid, v);
+    fft_pass<float, 13, 3, false, true, PTV, NT, false, T0REGS>(lds, tw, twl, tid, v);
+#endif
+}
+

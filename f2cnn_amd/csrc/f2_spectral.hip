@@ -250,6 +250,8 @@ __device__ __forceinline__ cpx<float> spectral_bin(cpx<float> X, f2_f4 hu, cpx<f
     return {yr, yi};
 }
 
+#include "f2_fft13_merged.h"
+
 // w_k of bin k = tid + j NB0: w_tid exp(-2 pi i j / (2 R0))  (NB0 / M = 1 / (2 R0))
 template <int R0, int J = 0>
 __device__ __forceinline__ cpx<float> bin_w(cpx<float> w0, int j) {
@@ -414,7 +416,8 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     // derived - and the LDS addresses are then not formed while the previous phase still needs the registers)
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e), "+v"(v[0].re), "+v"(v[PT - 1].im));
-    fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, v);
+    if constexpr (LOG2H == 13) fft13_regs_to_regs<PT, NT, T0R>(lds, tw, twl, tid_e, v);
+    else fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, v);
     // the last pass left sample m = tid + j NB0 in v[brev(j)]
     float er[NBLK], ei[NBLK];
 #pragma unroll
@@ -436,7 +439,8 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     F2_SSTAMP(4);
     int tid_o = tid;
     asm volatile("" : "+v"(tid_o), "+v"(v[0].re), "+v"(v[PT - 1].im));
-    fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_o, v);
+    if constexpr (LOG2H == 13) fft13_regs_to_regs<PT, NT, T0R>(lds, tw, twl, tid_o, v);
+    else fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_o, v);
     F2_SSTAMP(5);
 #pragma unroll
     for (int j = 0; j < R0; ++j) {
