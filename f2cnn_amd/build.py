@@ -14,7 +14,8 @@ ARCH = "gfx950"
 # v_mov than it saves (packed f32 VALU has no rate advantage at >= 2 waves/SIMD on gfx950).
 PER_FILE_FLAGS = {"f2_envelope.hip": ("-fno-slp-vectorize",),
                   "f2_envelope_large.hip": ("-fno-slp-vectorize",), "f2_envelope_split.hip": ("-fno-slp-vectorize",),
-                  "f2_envelope_pair.hip": ("-fno-slp-vectorize",), "f2_envelope_p3.hip": ("-fno-slp-vectorize",)}
+                  "f2_envelope_pair.hip": ("-fno-slp-vectorize",), "f2_envelope_p3.hip": ("-fno-slp-vectorize",),
+                  "f2_envelope_flagged.hip": ("-fno-slp-vectorize",), "f2_spectral.hip": ("-fno-slp-vectorize",)}
 
 
 def hipcc_path():

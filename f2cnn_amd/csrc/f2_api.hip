@@ -145,6 +145,8 @@ int f2_ctx_destroy(f2_ctx* ctx) {
             if (s.ptr) (void)hipFree(s.ptr);
     for (f2_scratch& s : ctx->tw_p3)
         if (s.ptr) (void)hipFree(s.ptr);
+    for (f2_scratch& s : ctx->tw_fl)
+        if (s.ptr) (void)hipFree(s.ptr);
     for (f2_scratch& s : ctx->tw_split)
         if (s.ptr) (void)hipFree(s.ptr);
     for (f2_scratch* sc : {&ctx->tw_pair[0], &ctx->tw_pair[1], &ctx->pair_list[0], &ctx->pair_list[1]})

@@ -56,8 +56,14 @@ namespace {
 #endif
 
 
+// (f2_envelope_flagged.hip compiles this file once more with F2_ENVELOPE_FLAGGED_TU: the body below then becomes the
+// device function envelope_row(P, tw, u, c) that its looping kernel calls; this translation unit's kernel is unchanged)
 template <typename F, int LOG2H>
+#ifdef F2_ENVELOPE_FLAGGED_TU
+__device__ __forceinline__ void envelope_row(const EnvParams& P, const cpx<F>* __restrict__ tw, const int u, const int c) {
+#else
 __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>())) void k_envelope(EnvParams P, const cpx<F>* __restrict__ tw) {
+#endif
     constexpr int NT = threads_for<F, LOG2H>();
     constexpr int H = 1 << LOG2H;
     constexpr int M = 2 * H;
@@ -82,8 +88,10 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
     const cpx<F>* __restrict__ V = tw + plan_tw_total(LOG2H);   // exp(-2 pi i k / M), k <= H/2
 
     const int tid = threadIdx.x;
+#ifndef F2_ENVELOPE_FLAGGED_TU
     const int u = blockIdx.x / P.C;
     const int c = blockIdx.x - u * P.C;
+#endif
     const int b = P.ulist ? P.ulist[u] : u;
     if (P.uflag && !P.uflag[b]) return;   // (whole workgroup) this utterance was served by the spectral kernel
     const int64_t off = P.offsets[b];
@@ -387,6 +395,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
 #endif
 }
 
+#ifndef F2_ENVELOPE_FLAGGED_TU
 template <typename F>
 using EnvKernel = void (*)(EnvParams, const cpx<F>*);
 
@@ -404,9 +413,45 @@ EnvKernel<F> kernel_for(int log2h) {
 constexpr int MAX_LOG2H_F32 = 14;  // rows up to 32768 samples
 constexpr int MAX_LOG2H_F64 = 13;  // rows up to 16384 samples
 
+#endif  // !F2_ENVELOPE_FLAGGED_TU
+
+#ifdef F2_ENVELOPE_FLAGGED_TU
+// The rows of a length class for launches that exist to serve utterances the spectral kernel's accuracy guard sends back
+// (normally none): one workgroup per (utterance, slice of C / ENV_SLICES channels) that leaves at once when its utterance
+// is not flagged and otherwise walks its channels. 1 / 16 of k_envelope's workgroups to dispatch when there is nothing to
+// do (5 us instead of 75 us per 1000 x 128 rows), and a flagged utterance still spreads over ENV_SLICES workgroups.
+constexpr int ENV_SLICES = 8;
+template <typename F, int LOG2H>
+__global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>())) void k_envelope_flagged(EnvParams P, const cpx<F>* __restrict__ tw) {
+    const int u = blockIdx.x / ENV_SLICES, sl = blockIdx.x - u * ENV_SLICES;
+    const int b = P.ulist ? P.ulist[u] : u;
+    if (!P.uflag[b]) return;
+    const int per = (P.C + ENV_SLICES - 1) / ENV_SLICES;
+    for (int c = sl * per; c < min(P.C, (sl + 1) * per); ++c) {
+        envelope_row<F, LOG2H>(P, tw, u, c);
+        __syncthreads();   // the next row reuses the LDS arrays
+    }
+}
+#endif
+
 }  // namespace
 
-#ifdef F2_ENVELOPE_P3_TU
+#ifdef F2_ENVELOPE_FLAGGED_TU
+int f2_launch_envelope_flagged(f2_ctx* ctx, const f2_env_params& P, int log2h, unsigned nutt) {
+    F2_CHECK(ctx, P.uflag && log2h >= F2_SPECTRAL_MIN_LOG2H && log2h <= F2_SPECTRAL_MAX_LOG2H, F2_ERR_INVALID,
+             "flagged-row launch outside the spectral kernel's length classes");
+    F2_TRY(ensure_twiddles<float>(ctx, log2h, ctx->tw_fl[log2h]));
+    const cpx<float>* tw = (const cpx<float>*)ctx->tw_fl[log2h].ptr;
+    const dim3 grid(nutt * ENV_SLICES);
+    switch (log2h) {
+        case 12: hipLaunchKernelGGL((k_envelope_flagged<float, 12>), grid, dim3(threads_for<float, 12>()), 0, ctx->stream, P, tw); break;
+        case 13: hipLaunchKernelGGL((k_envelope_flagged<float, 13>), grid, dim3(threads_for<float, 13>()), 0, ctx->stream, P, tw); break;
+        default: hipLaunchKernelGGL((k_envelope_flagged<float, 14>), grid, dim3(threads_for<float, 14>()), 0, ctx->stream, P, tw); break;
+    }
+    F2_HIP(ctx, hipGetLastError());
+    return F2_OK;
+}
+#elif defined(F2_ENVELOPE_P3_TU)
 int f2_launch_envelope13_p3(f2_ctx* ctx, const f2_env_params& P, int precision, unsigned rows) {
     constexpr int L13 = 13;
     static_assert(plan_npass(L13) == 3, "this translation unit is compiled with the three-pass plan");
@@ -522,7 +567,11 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
                              : (log2h == 13 && precision == F2_FFT_F32) ? F2_THREADS13 : log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
         const dim3 grid((unsigned)(g.size() * (size_t)C)), block(nthreads);
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
-        if (log2h == 13 && (!P.lpf || precision == F2_FFT_F64) && !ctx->opt_env_plan4) {
+        if (precision == F2_FFT_F32 && P.uflag && log2h >= F2_SPECTRAL_MIN_LOG2H && log2h <= F2_SPECTRAL_MAX_LOG2H) {
+            // a length class the spectral kernel serves: its utterances only come here when the guard flags them (or the
+            // host routed them here: too little padding) - walked by far fewer workgroups (f2_envelope_flagged.hip)
+            F2_TRY(f2_launch_envelope_flagged(ctx, P, log2h, (unsigned)g.size()));
+        } else if (log2h == 13 && (!P.lpf || precision == F2_FFT_F64) && !ctx->opt_env_plan4) {
             // the 1 s row without the float low-pass: three-pass plan (f2_envelope_p3.hip)
             F2_TRY(f2_launch_envelope13_p3(ctx, P, precision, (unsigned)(g.size() * (size_t)C)));
         } else if (precision == F2_FFT_F32) {

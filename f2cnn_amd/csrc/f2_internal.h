@@ -43,6 +43,7 @@ struct f2_ctx {
     f2_scratch work2;
     f2_scratch xbuf;       // window tensor chunk between K3 and K4
     f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
+    f2_scratch tw_fl[16];         // twiddle tables of f2_envelope_flagged.hip, by log2 H
     f2_scratch tw_p3[2];   // the same for the three-pass plan of H = 8192 (f2_envelope_p3.hip), [precision]
     f2_scratch tw_large[2][24];   // same for the global-memory transform of long rows
     f2_scratch tw_split[24];      // tables of the four-step transform (f2_envelope_split.hip), by log2 H
@@ -148,6 +149,8 @@ struct f2_env_params {
 // macro - and exports only this launcher. Measured against the four-pass plan: 8 % faster without the low-pass, 6 % with
 // the float64 transform, 4 % slower with the float low-pass; f2_launch_envelope picks per call.
 int f2_launch_envelope13_p3(f2_ctx* ctx, const f2_env_params& P, int precision, unsigned rows);
+// f2_envelope_flagged.hip: the utterances P.ulist[0..nutt) of length class log2h whose P.uflag entry is set (float FFT)
+int f2_launch_envelope_flagged(f2_ctx* ctx, const f2_env_params& P, int log2h, unsigned nutt);
 
 // longest row (2^22 samples = 262 s at 16 kHz) the global-memory envelope path accepts
 // rows between the LDS limit and 262144 samples: four-step transform with LDS-resident 4096-point parts

@@ -16,9 +16,10 @@
 // the ringing after sample n (which a circular product alone would wrap around). Q is evaluated through its D-adic
 // digits  Q = r_0 + r_1 D + r_2 D^2 + r_3 D^3  (deg r_j <= 1):  u^4 Q = u (r_3 + u (r_2 + u (r_1 + u r_0))), a Horner
 // chain without cancellation (the monomial form of Q loses 1/|D|^3 ~ 1e9 near the resonance of the low channels).
-// The state words at sample n only depend on the last L samples of the utterance (poles of radius r: n^3 r^n < 1e-10
-// of its peak beyond L; L = 150 ... 2400 samples for the 128-channel bank): k_tail_state runs the float64 recurrences
-// of K1 over those samples only and leaves the eight digit coefficients of every row.
+// The state words at sample n only depend on the last L samples of the utterance (poles of radius r: n^3 r^n < 1e-8
+// of its peak beyond L; L = 130 ... 2100 samples for the 128-channel bank): k_tail_state runs the float64 recurrences
+// of K1 over those samples only and leaves the eight digit coefficients of every row. (The kernel is bound by float64
+// throughput, not by the length of its serial runs: splitting every run into four chained segments made it slower.)
 //
 // The analytic signal a = IDFT_M of the one-sided spectrum A (A(k) = 2 Y(k), 0 < k < H; Y(0); Y(H)) is computed for the
 // even and the odd samples by two H-point complex transforms,  a[2m] = IDFT_H(A_e)[m], A_e(k) = A(k) (k = 0: A(0) + A(H)),
@@ -769,7 +770,7 @@ bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::ve
         if (k[5] != 0.0 || k[0] == 0.0 || k[6] == 0.0 || k[9] == 0.0) return false;
         for (int q = 0; q < 10; ++q)
             if (!std::isfinite(k[q])) return false;
-        const int64_t L = ringing_length(k[7] / k[6], k[8] / k[6], 1e-10, int64_t(1) << 17);
+        const int64_t L = ringing_length(k[7] / k[6], k[8] / k[6], 1e-8, int64_t(1) << 17);
         if (L <= 0) return false;
         if (Lgroup) (*Lgroup)[(size_t)c / 64] = std::max((*Lgroup)[(size_t)c / 64], (int)L);
     }

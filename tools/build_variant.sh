@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p /tmp/f2var_$name
 for f in f2cnn_amd/csrc/*.hip; do
-  extra=""; case "$f" in *envelope*) extra="-fno-slp-vectorize";; esac
+  extra=""; case "$f" in *envelope*|*spectral*) extra="-fno-slp-vectorize";; esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 "$@" $extra -c "$f" -o /tmp/f2var_$name/$(basename "$f" .hip).o &
 done
 wait
