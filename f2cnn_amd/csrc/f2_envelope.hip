@@ -438,7 +438,7 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
 
 #ifdef F2_ENVELOPE_FLAGGED_TU
 int f2_launch_envelope_flagged(f2_ctx* ctx, const f2_env_params& P, int log2h, unsigned nutt) {
-    F2_CHECK(ctx, P.uflag && log2h >= F2_SPECTRAL_MIN_LOG2H && log2h <= F2_SPECTRAL_MAX_LOG2H, F2_ERR_INVALID,
+    F2_CHECK(ctx, P.uflag && log2h >= F2_SPECTRAL_MIN_LOG2H && log2h <= 14, F2_ERR_INVALID,
              "flagged-row launch outside the spectral kernel's length classes");
     F2_TRY(ensure_twiddles<float>(ctx, log2h, ctx->tw_fl[log2h]));
     const cpx<float>* tw = (const cpx<float>*)ctx->tw_fl[log2h].ptr;
@@ -532,7 +532,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
             F2_TRY(f2_launch_envelope_pair(ctx, d_gfb, d_env, d_offsets, h_offsets, pair_group[g].data(),
                                            (int)pair_group[g].size(), 14 + g, C, P.lpf, P.b0, P.a1,
                                            f32_in ? handoff->d_x32 : nullptr, f32_in ? handoff->d_x32_off : nullptr,
-                                           f32_in ? handoff->h_x32_off : nullptr));
+                                           f32_in ? handoff->h_x32_off : nullptr, d_uflag));
     for (int log2h = 0; log2h < 32; ++log2h)
         if (!split_groups[log2h].empty())
             F2_TRY(f2_launch_envelope_split(ctx, d_gfb, d_env, d_offsets, split_groups[log2h].data(),
@@ -567,7 +567,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
                              : (log2h == 13 && precision == F2_FFT_F32) ? F2_THREADS13 : log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
         const dim3 grid((unsigned)(g.size() * (size_t)C)), block(nthreads);
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
-        if (precision == F2_FFT_F32 && P.uflag && log2h >= F2_SPECTRAL_MIN_LOG2H && log2h <= F2_SPECTRAL_MAX_LOG2H) {
+        if (precision == F2_FFT_F32 && P.uflag && log2h >= F2_SPECTRAL_MIN_LOG2H && log2h <= 14) {
             // a length class the spectral kernel serves: its utterances only come here when the guard flags them (or the
             // host routed them here: too little padding) - walked by far fewer workgroups (f2_envelope_flagged.hip)
             F2_TRY(f2_launch_envelope_flagged(ctx, P, log2h, (unsigned)g.size()));

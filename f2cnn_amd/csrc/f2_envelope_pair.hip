@@ -48,6 +48,7 @@ struct PairParams {
     double* env;
     const int64_t* offsets;
     const int* ulist;          // utterances of this launch (device)
+    const int* uflag;          // per utterance of the batch, or NULL: utterances whose flag is 0 are left alone
     int C;
     int lpf;
     double b0, a1;
@@ -151,6 +152,7 @@ __global__ __launch_bounds__((Geo<LOG2S>::NT), 4) void k_envelope_pair(PairParam
     const int tid = threadIdx.x;
     const int u = blockIdx.x / P.C, c = blockIdx.x - u * P.C;
     const int b = P.ulist[u];
+    if (P.uflag && !P.uflag[b]) return;   // (whole workgroup) served by the spectral kernel
     const int64_t off = P.offsets[b];
     const int n = (int)(P.offsets[b + 1] - off);
     const size_t row = (size_t)P.C * (size_t)off + (size_t)c * (size_t)n;
@@ -285,15 +287,21 @@ int ensure_pair_tables(f2_ctx* ctx, f2_scratch& slot) {
 template <int LOG2S>
 int launch_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets, const int64_t* h_offsets,
                 const int* utts, int nutt, int C, int lpf, double b0, double a1, const float* d_x32,
-                const int64_t* d_x32_off, const int64_t* h_x32_off) {
+                const int64_t* d_x32_off, const int64_t* h_x32_off, const int* d_uflag) {
     constexpr int HS = Geo<LOG2S>::HS, NT = Geo<LOG2S>::NT;
     f2_scratch& tables = ctx->tw_pair[LOG2S - 13];
     F2_TRY(ensure_pair_tables<LOG2S>(ctx, tables));
     F2_TRY(ensure_twiddles<float>(ctx, LOG2S, ctx->tw[0][LOG2S]));
     f2_scratch& list = ctx->pair_list[LOG2S - 13];
-    F2_TRY(f2_reserve(ctx, list, sizeof(int) * (size_t)nutt));
-    F2_HIP(ctx, hipMemcpyAsync(list.ptr, utts, sizeof(int) * (size_t)nutt, hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `utts` belongs to the caller
+    std::vector<int>& list_host = ctx->pair_list_host[LOG2S - 13];
+    if (!list.ptr || list_host.size() != (size_t)nutt || memcmp(list_host.data(), utts, sizeof(int) * (size_t)nutt) != 0) {
+        // (same batch shape as the previous call: the device copy is still valid and the call only enqueues)
+        list_host.clear();
+        F2_TRY(f2_reserve(ctx, list, sizeof(int) * (size_t)nutt));
+        F2_HIP(ctx, hipMemcpyAsync(list.ptr, utts, sizeof(int) * (size_t)nutt, hipMemcpyHostToDevice, ctx->stream));
+        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `utts` belongs to the caller
+        list_host.assign(utts, utts + nutt);
+    }
     PairParams P;
     P.gfb = d_gfb;
     P.env = d_env;
@@ -308,6 +316,7 @@ int launch_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* 
     P.tx = (const cpx<float>*)tables.ptr;
     P.vo = P.tx + HS;
     P.ulist = (const int*)list.ptr;
+    P.uflag = d_uflag;
     P.stamps = nullptr;
 #ifdef F2_STAMPS
     static unsigned long long* d_stamps = nullptr;
@@ -354,9 +363,11 @@ bool f2_envelope_pair_supports(int log2h, int precision) { return precision == F
 // All utterances `utts` have the same transform size 2^log2h complex points.
 int f2_launch_envelope_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets,
                             const int64_t* h_offsets, const int* utts, int nutt, int log2h, int C, int lpf, double b0,
-                            double a1, const float* d_x32, const int64_t* d_x32_off, const int64_t* h_x32_off) {
+                            double a1, const float* d_x32, const int64_t* d_x32_off, const int64_t* h_x32_off,
+                            const int* d_uflag) {
     if (nutt <= 0) return F2_OK;
     F2_CHECK(ctx, d_x32 || d_gfb != d_env, F2_ERR_INVALID, "the two-sub-row envelope path cannot run in place");
     F2_CHECK(ctx, f2_envelope_pair_supports(log2h, F2_FFT_F32), F2_ERR_INVALID, "unsupported size 2^%d", log2h);
-    return launch_pair<14>(ctx, d_gfb, d_env, d_offsets, h_offsets, utts, nutt, C, lpf, b0, a1, d_x32, d_x32_off, h_x32_off);
+    return launch_pair<14>(ctx, d_gfb, d_env, d_offsets, h_offsets, utts, nutt, C, lpf, b0, a1, d_x32, d_x32_off, h_x32_off,
+                           d_uflag);
 }

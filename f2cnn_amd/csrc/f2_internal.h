@@ -47,6 +47,7 @@ struct f2_ctx {
     f2_scratch tw_p3[2];   // the same for the three-pass plan of H = 8192 (f2_envelope_p3.hip), [precision]
     f2_scratch tw_large[2][24];   // same for the global-memory transform of long rows
     f2_scratch tw_split[24];      // tables of the four-step transform (f2_envelope_split.hip), by log2 H
+    std::vector<int> pair_list_host[2];   // what pair_list currently holds (skip the upload when equal)
     f2_scratch tw_pair[2], pair_list[2];   // two-sub-row transform of 16385..65536-sample rows (f2_envelope_pair.hip): tables, utterance lists
     f2_scratch work3;             // utterance lists of the four-step launches
     f2_scratch handoff, handoff_off;   // float32 hand-off of long rows (f2_plan_handoff)
@@ -162,7 +163,8 @@ int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, co
 bool f2_envelope_pair_supports(int log2h, int precision);
 int f2_launch_envelope_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets,
                             const int64_t* h_offsets, const int* utts, int nutt, int log2h, int C, int lpf, double b0,
-                            double a1, const float* d_x32, const int64_t* d_x32_off, const int64_t* h_x32_off);
+                            double a1, const float* d_x32, const int64_t* d_x32_off, const int64_t* h_x32_off,
+                            const int* d_uflag = nullptr);
 #define F2_MAX_LOG2M_LARGE 22
 int f2_launch_envelope_large(f2_ctx* ctx, const double* d_x, double* d_y, int64_t n, int C, int lpf, double b0,
                              double a1, int precision);

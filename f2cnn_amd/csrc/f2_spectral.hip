@@ -495,6 +495,10 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
 #endif
 }
 
+// (Rows of 32769..65536 samples - four 16384-point sub-transforms per row from a spectrum parked in the row's output slot,
+// quad low-pass - were built and verified in round 3 and taken out again: with 4 x 16 magnitudes to keep next to the
+// transform's 64 + 32 registers the 1024-thread workgroup spilled 150 registers and ran at 195 us per row against ~100 us for
+// the filterbank kernel + on-chip pair kernel it was to replace. DESIGN.md section 7.)
 // ---- X = DFT_M(x zero-padded), k = 0..H, float64 arithmetic, float32 out ----
 // (float64: the float32 rounding of a transform is relative to the LOUDEST band of the utterance; a channel that sits
 // 60 dB below it - speech above 4 kHz - would inherit 1e-4 of its own level.)
@@ -856,32 +860,35 @@ static int spectral_tables(f2_ctx* ctx, int C, int log2h, f2_spec_tables** out) 
     return F2_OK;
 }
 
-// powers of q = -a1 every thread needs (lowpass_pairs_store_tab), cached per a1
-static int lowpass_table(f2_ctx* ctx, double a1, double b0, int nt, LowpassConsts* K) {
+// powers of q = -a1 every thread needs (lowpass_pairs_store_tab: sp = 2 samples per thread and block), cached per a1
+static int lowpass_table(f2_ctx* ctx, double a1, double b0, int nt, int sp, LowpassConsts* K, const f2_f4** d_tab) {
     const long double q = -(long double)a1;
     K->qf = (float)q;
     K->b0f = (float)b0;
-    K->g1 = (float)powl(q, 2);
-    K->g2 = (float)powl(q, 4);
-    K->g4 = (float)powl(q, 8);
-    K->g8 = (float)powl(q, 16);
-    K->gw = (double)powl(q, 128);
-    K->gblk = (double)powl(q, 2 * nt);
+    K->g1 = (float)powl(q, sp);
+    K->g2 = (float)powl(q, 2 * sp);
+    K->g4 = (float)powl(q, 4 * sp);
+    K->g8 = (float)powl(q, 8 * sp);
+    K->gw = (double)powl(q, 64 * sp);
+    K->gblk = (double)powl(q, sp * nt);
+    f2_scratch& slot = ctx->spec_lptab;
+    double& slot_a1 = ctx->spec_lptab_a1;
+    *d_tab = (const f2_f4*)slot.ptr;
     constexpr int TMAX = 1024;   // the per-thread entries do not depend on the workgroup size: one table serves all
-    if (ctx->spec_lptab.ptr && ctx->spec_lptab_a1 == a1 && ctx->spec_lptab_nt == TMAX) return F2_OK;
+    if (slot.ptr && slot_a1 == a1) return F2_OK;
     std::vector<float> tab((size_t)TMAX * 4);
     for (int t = 0; t < TMAX; ++t) {
         const int lane = t & 63;
-        tab[4 * (size_t)t] = (float)powl(q, 2 * (lane + 1));
-        tab[4 * (size_t)t + 1] = (float)powl(q, 2 * t);
-        tab[4 * (size_t)t + 2] = (float)powl(q, 2 * ((lane & 15) + 1));
-        tab[4 * (size_t)t + 3] = (float)powl(q, 2 * ((lane & 31) + 1));
+        tab[4 * (size_t)t] = (float)powl(q, sp * (lane + 1));
+        tab[4 * (size_t)t + 1] = (float)powl(q, sp * t);
+        tab[4 * (size_t)t + 2] = (float)powl(q, sp * ((lane & 15) + 1));
+        tab[4 * (size_t)t + 3] = (float)powl(q, sp * ((lane & 31) + 1));
     }
-    F2_TRY(f2_reserve(ctx, ctx->spec_lptab, sizeof(float) * tab.size()));
-    F2_HIP(ctx, hipMemcpyAsync(ctx->spec_lptab.ptr, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    F2_TRY(f2_reserve(ctx, slot, sizeof(float) * tab.size()));
+    F2_HIP(ctx, hipMemcpyAsync(slot.ptr, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
     F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `tab` is a local (one-time per cutoff)
-    ctx->spec_lptab_a1 = a1;
-    ctx->spec_lptab_nt = TMAX;
+    slot_a1 = a1;
+    *d_tab = (const f2_f4*)slot.ptr;
     return F2_OK;
 }
 
@@ -894,8 +901,9 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
     F2_TRY(spectral_tables(ctx, C, LOG2H, &tab));
     // float64 transform of the utterances: 2^13 packed complex points fit in LDS; longer rows are decimated in time
     constexpr int LOGD = LOG2H > 13 ? LOG2H - 13 : 0, LOG2HS = LOG2H - LOGD;
+    constexpr int FFTLOG = LOG2H;
     F2_TRY(ensure_twiddles<double>(ctx, LOG2HS, ctx->tw_sp[1][LOG2HS]));
-    F2_TRY(ensure_twiddles<float>(ctx, LOG2H, ctx->tw_sp[0][LOG2H]));
+    F2_TRY(ensure_twiddles<float>(ctx, FFTLOG, ctx->tw_sp[0][FFTLOG]));
     const int64_t xpitch = H + 8;
     const int groups = (C + 63) / 64;
     F2_TRY(f2_prof_begin(ctx, F2_K_SPECTRUM));
@@ -929,7 +937,8 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
     P.C = C;
     P.nutt = nutt;
     P.lpf = lpf;
-    F2_TRY(lowpass_table(ctx, a1, b0, threads_for<float, LOG2H>(), &P.lp));
+    const f2_f4* d_lptab = nullptr;
+    F2_TRY(lowpass_table(ctx, a1, b0, threads_for<float, FFTLOG>(), 2, &P.lp, &d_lptab));
     P.tol = tol;
     P.stamps = nullptr;
 #ifdef F2_STAMPS
@@ -939,10 +948,9 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
     if (nstamp <= (size_t)8 * 128 * 2048) P.stamps = d_stamps;
 #endif
     F2_TRY(f2_prof_begin(ctx, F2_K_FUSED));
-    hipLaunchKernelGGL((k_spectral_envelope<LOG2H>), dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, LOG2H>()), 0,
+    hipLaunchKernelGGL((k_spectral_envelope<FFTLOG>), dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, FFTLOG>()), 0,
                        ctx->stream, P, (const cpx<float>*)d_X, (const f2_f4*)tab->hu.ptr, (const cpx<float>*)tab->e.ptr,
-                       (const float*)d_rho, d_offsets, d_ulist, (const f2_f4*)ctx->spec_lptab.ptr,
-                       (const cpx<float>*)ctx->tw_sp[0][LOG2H].ptr);
+                       (const float*)d_rho, d_offsets, d_ulist, d_lptab, (const cpx<float>*)ctx->tw_sp[0][FFTLOG].ptr);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_FUSED));
 #ifdef F2_STAMPS

@@ -38,7 +38,7 @@ def test_ragged_batch_against_oracle_and_two_kernel_route(lpf):
     ctx = _lib.default_context()
     coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
     lens = [16000, 15999, 9000, 8193, 16320, 16321, 4097, 5000, 8128, 8129, 300, 16384, 20000, 1, 32704, 32705, 16385,
-            27001, 40000]
+            27001, 40000, 32769]
     waves = [orc.synth_utterance(500 + i, n) for i, n in enumerate(lens)]
     got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
     old, _ = fused(ctx, waves, coefs, lpf, spectral=0)
@@ -89,10 +89,12 @@ def test_accuracy_guard_sends_a_late_click_back():
     coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
     click = np.zeros(16000, np.int16)
     click[15990] = 32767
-    waves = [orc.synth_utterance(1, 16000), click, orc.synth_utterance(2, 12000)]
+    click2 = np.zeros(30000, np.int16)          # the same in the 16385..32768-sample class
+    click2[29995] = 32767
+    waves = [orc.synth_utterance(1, 16000), click, orc.synth_utterance(2, 12000), click2, orc.synth_utterance(3, 50001)]
     for lpf in (False, True):
         got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
-        assert flagged == 1
+        assert flagged == 2
         for w, g in zip(waves, got):
             assert chan_relerr(g, orc.filter_and_envelope(w, coefs, lpf, 50)) <= TOL
     # with the guard disabled the click really is out of tolerance on the spectral path (the guard is not idle)
