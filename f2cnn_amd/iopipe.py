@@ -245,13 +245,19 @@ def _pinned(nbytes):
     return _lib.default_context().host_alloc(nbytes)
 
 
-host_pool = ArrayPool(keep=16, alloc=_pinned)
+host_pool = ArrayPool(keep=int(os.environ.get("F2CNN_POOL_KEEP", "16")), alloc=_pinned)
 
 
 def save_npy_atomic(filename, array):
     """numpy.save(filename, array) that never leaves a partial file under the final name: the array goes to
-    `<name>.tmp.<pid>` in the same directory and is renamed over the target (os.replace) once it is complete, so
-    `--skip-existing` can trust every file it finds. `filename` gets the `.npy` suffix numpy.save would add."""
+    `<name>.tmp.<pid>` in the same directory and is renamed over the target (os.replace) once it is complete.
+    `filename` gets the `.npy` suffix numpy.save would add.
+
+    For single outputs. The batch writers of `prepare filter / envelope / features` do NOT use it: twelve writer threads
+    creating and renaming 16 MB files in one tmpfs directory ran the whole pipeline at 0.4x the rate of in-place
+    numpy.save (measured, same box: 290-360 against 680-990 audio-s/s). Their protection against a killed run is
+    JobReport.pending(): with --skip-existing an output only counts as done when its NPY header fits the file size
+    (npy_complete), which a partially written file never satisfies."""
     final = filename if str(filename).endswith(".npy") else str(filename) + ".npy"
     tmp = "{}.tmp.{}".format(final, os.getpid())
     try:

@@ -13,7 +13,7 @@ import numpy
 
 from ... import _lib
 from ...config import F2Config
-from ...iopipe import JobReport, Unreadable, host_pool, npy_layout, read_npy_into, run_batches, save_npy_atomic
+from ...iopipe import JobReport, Unreadable, host_pool, npy_layout, read_npy_into, run_batches
 from ...runtime import shard_for_rank
 
 FFT_PRECISION = _lib.FFT_F64 if os.environ.get("F2CNN_FFT", "f32").lower() in ("f64", "double") else _lib.FFT_F32
@@ -66,7 +66,7 @@ def envelope_filename(gfbFileName):
 
 
 def SaveEnvelope(matrix, gfbFileName, nbf=None, done=None):
-    save_npy_atomic(envelope_filename(gfbFileName), matrix)
+    numpy.save(envelope_filename(gfbFileName), matrix)
     if nbf is not None:
         print("\t{:<50} done ! {}/{} Files.".format(envelope_filename(gfbFileName), done, nbf))
 
@@ -154,7 +154,7 @@ def ExtractAllEnvelopes(LPF=False, CUTOFF=100, batch_files=16, skip_existing=Fal
         return finish
 
     def save(name, e):
-        save_npy_atomic(envelope_filename(name), e)
+        numpy.save(envelope_filename(name), e)
         print("\t{:<50} done ! {}/{} Files.".format(envelope_filename(name), report.add(e.shape[1], framerate), len(mine)))
 
     run_batches(mine, report.guard(load), compute, save, batch=batch_files, plan=plan)
@@ -227,8 +227,8 @@ def FilterAndExtractAll(LPF=False, CUTOFF=100, batch_files=16, keep_gfb=True, sk
         env, gfb = res
         base = os.path.splitext(name)[0]
         if gfb is not None:
-            save_npy_atomic(base + '.GFB', gfb)
-        save_npy_atomic(base + '.ENV' + str(METHOD), env)
+            numpy.save(base + '.GFB', gfb)
+        numpy.save(base + '.ENV' + str(METHOD), env)
         print("\t{:<50} done ! {}/{} Files.".format(base + '.ENV' + str(METHOD), report.add(env.shape[1], rates[name]),
                                                      len(mine)))
 

@@ -13,7 +13,7 @@ import numpy
 from ... import _lib
 from ...config import F2Config
 from ...gammatone import filters
-from ...iopipe import JobReport, Unreadable, host_pool, run_batches, save_npy_atomic
+from ...iopipe import JobReport, Unreadable, host_pool, run_batches
 from ...runtime import shard_for_rank
 from ...wavio import read_audio
 
@@ -33,7 +33,7 @@ def GetFilteredOutputFromFile(filename, FILTERBANK_COEFFICIENTS):
 
 
 def saveGFBMatrix(filename, matrix):
-    save_npy_atomic(filename, matrix)
+    numpy.save(filename, matrix)   # (in place: see iopipe.save_npy_atomic for why the batch writers do not rename)
 
 
 def loadGFBMatrix(filename):
