@@ -87,6 +87,52 @@ __device__ __forceinline__ void fft13_pass12_merged(cpx<float>* lds, const cpx<f
     __syncthreads();
 }
 
+// First pass of TWO 8192-point transforms of the same workgroup at once (the even-sample and the odd-sample transform
+// of k_spectral_envelope): thread t runs butterfly t of both, so the fifteen twiddles it derives from two loaded ones
+// (f2_fft_lds.h, T0REGS) serve both - 52 instructions and two loads less per row and thread than two separate first
+// passes. The outputs stay in registers (v[brev<16>(k)] = output k); fft13_from_pass0 takes a transform from there.
+template <int NT, int PTV>
+__device__ __forceinline__ void fft13_pass0_pair(const cpx<float>* __restrict__ tw, int tid, cpx<float> (&va)[PTV], cpx<float> (&vb)[PTV]) {
+    constexpr int LOG2H = 13, R = 16, NB = (1 << LOG2H) / R;
+    static_assert(NT == NB && PTV == R && plan_bits(LOG2H, 0) == 4, "one radix-16 butterfly per thread");
+    dft<R>(&va[0]);
+    dft<R>(&vb[0]);
+    const cpx<float>* twq = tw + plan_tw_offset(LOG2H, 0) + tid;
+    cpx<float> w[R];
+    w[1] = twq[0];
+    w[4] = twq[3 * NB];
+    w[2] = cmul(w[1], w[1]);
+    w[3] = cmul(w[2], w[1]);
+    w[8] = cmul(w[4], w[4]);
+    w[5] = cmul(w[4], w[1]);
+    w[6] = cmul(w[4], w[2]);
+    w[7] = cmul(w[4], w[3]);
+    w[12] = cmul(w[8], w[4]);
+    w[9] = cmul(w[8], w[1]);
+    w[10] = cmul(w[8], w[2]);
+    w[11] = cmul(w[8], w[3]);
+    w[13] = cmul(w[12], w[1]);
+    w[14] = cmul(w[12], w[2]);
+    w[15] = cmul(w[12], w[3]);
+#pragma unroll
+    for (int k = 1; k < R; ++k) {
+        va[brev<R>(k)] = cmul(va[brev<R>(k)], w[k]);
+        vb[brev<R>(k)] = cmul(vb[brev<R>(k)], w[k]);
+    }
+}
+
+// the rest of an 8192-point transform whose first pass (fft13_pass0_pair) left its outputs in v: exchange, merged passes
+// 1 + 2, last pass; results in v as fft_regs_to_regs leaves them
+template <int PTV, int NT, bool T0REGS>
+__device__ __forceinline__ void fft13_from_pass0(cpx<float>* lds, const cpx<float>* __restrict__ tw, const cpx<float>* twl, int tid,
+                                                 cpx<float> (&v)[PTV]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[cpad(tid * 16 + k)] = v[brev<16>(k)];     // pass 0 has stride 1: outputs 16 t + k
+    __syncthreads();
+    fft13_pass12_merged<NT, PTV>(lds, twl, tid, v);
+    fft_pass<float, 13, 3, false, true, PTV, NT, false, T0REGS>(lds, tw, twl, tid, v);
+}
+
 // the whole 8192-point transform, registers (first-pass layout) to registers (as fft_regs_to_regs leaves them)
 template <int PTV, int NT, bool T0REGS>
 __device__ __forceinline__ void fft13_regs_to_regs(cpx<float>* lds, const cpx<float>* __restrict__ tw, const cpx<float>* twl, int tid,

@@ -408,11 +408,49 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         const cpx<float> yh = spectral_bin(XH, HUH, cpx<float>{-1.f, 0.f}, cpx<float>{(n & 1) ? -1.f : 1.f, 0.f}, rho);
         yk[0] = {yk[0].re, yh.re};
     }
+    float er[NBLK], ei[NBLK];
+    float pad_e, pad_o;
+    constexpr bool T0R = derive_tw0<float, LOG2H>();
+    if constexpr (LOG2H == 13) {
+        // 2 + 3 (8192-point rows): both transforms' inputs formed at once - conj(A_e) / M and conj(A_o) / M =
+        // conj(A) w_k / M - and their first passes run together (one set of derived twiddles); the odd transform's
+        // first-pass outputs then wait in the registers Y' occupied, while the even transform goes through LDS
+        cpx<float> vo[PT];
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+            const cpx<float> w = bin_w<R0>(w0, j);
+            const cpx<float> a = yk[j];
+            v[j] = {a.re, -a.im};
+            vo[j] = {a.re * w.re + a.im * w.im, a.re * w.im - a.im * w.re};
+        }
+        if (tid == 0) {
+            v[0] = {0.5f * (yk[0].re + yk[0].im), 0.f};
+            vo[0] = {0.5f * (yk[0].re - yk[0].im), 0.f};
+        }
+        F2_SSTAMP(4);
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e), "+v"(v[0].re), "+v"(vo[PT - 1].im));
+        fft13_pass0_pair<NT, PT>(tw, tid_e, v, vo);
+        fft13_from_pass0<PT, NT, T0R>(lds, tw, twl, tid_e, v);
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+            const cpx<float> a = v[brev<R0>(j)];
+            er[j] = fsqrt(a.re * a.re + a.im * a.im);
+        }
+        pad_e = fabsf(v[brev<R0>(R0 - 1)].re);
+        fft13_from_pass0<PT, NT, T0R>(lds, tw, twl, tid_e, vo);
+        F2_SSTAMP(5);
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+            const cpx<float> a = vo[brev<R0>(j)];
+            ei[j] = fsqrt(a.re * a.re + a.im * a.im);
+        }
+        pad_o = fabsf(vo[brev<R0>(R0 - 1)].re);
+    } else {
     // 2. even samples: conj(a[2m]) = DFT_H(conj(A_e) / M)
 #pragma unroll
     for (int q = 0; q < PT; ++q) v[q] = {yk[q].re, -yk[q].im};
     if (tid == 0) v[0] = {0.5f * (yk[0].re + yk[0].im), 0.f};
-    constexpr bool T0R = derive_tw0<float, LOG2H>();
     // (the thread index each transform works from is tied to its input: the first-pass twiddles - 30 registers once
     // derived - and the LDS addresses are then not formed while the previous phase still needs the registers)
     int tid_e = tid;
@@ -420,13 +458,12 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     if constexpr (LOG2H == 13) fft13_regs_to_regs<PT, NT, T0R>(lds, tw, twl, tid_e, v);
     else fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, v);
     // the last pass left sample m = tid + j NB0 in v[brev(j)]
-    float er[NBLK], ei[NBLK];
 #pragma unroll
     for (int j = 0; j < R0; ++j) {
         const cpx<float> a = v[brev<R0>(j)];
         er[j] = fsqrt(a.re * a.re + a.im * a.im);
     }
-    const float pad_e = fabsf(v[brev<R0>(R0 - 1)].re);   // |Re a| of the last block's even sample
+    pad_e = fabsf(v[brev<R0>(R0 - 1)].re);   // |Re a| of the last block's even sample
     // 3. odd samples: conj(a[2m+1]) = DFT_H(conj(A_o) / M), conj(A_o(k)) = conj(A(k)) w_k  (w_k formed again from
     //    w_tid: kept across the first transform they would cost 30 registers)
     asm volatile("" : "+v"(w0.re), "+v"(w0.im));
@@ -448,7 +485,8 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         const cpx<float> a = v[brev<R0>(j)];
         ei[j] = fsqrt(a.re * a.re + a.im * a.im);
     }
-    const float pad_o = fabsf(v[brev<R0>(R0 - 1)].re);
+    pad_o = fabsf(v[brev<R0>(R0 - 1)].re);
+    }
     // 4. accuracy guard: block jj of this thread is the sample pair 2 (tid + NT jj), + 1. Inside [0, n) the row's
     //    maximum; in the padding region the REAL part of a (the zero-padded row itself: zero in exact arithmetic, while
     //    the imaginary part, the Hilbert transform of a time-limited signal, is not) - sampled in the last block, which
