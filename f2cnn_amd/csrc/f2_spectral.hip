@@ -343,6 +343,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     static_assert(ITER0 == 1 && R0 == 16, "one radix-16 butterfly per thread in the first pass");
     constexpr int GB = F2_SPEC_GB, NG = R0 / GB;
     cpx<float> yk[PT], v[PT];
+    [[maybe_unused]] cpx<float> vo[PT];   // 8192-point rows: conj(A_o) / M, formed while the bin's phase factor is at hand
     const unsigned zstep = ((unsigned)NB0 * (unsigned)n) & (M - 1);
     cpx<float> w0 = E[tid];
     cpx<float> z0 = E[__umul24((unsigned)tid, (unsigned)n) & (M - 1)];
@@ -379,7 +380,9 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         for (int q = 0; q < GB; ++q) {
             const int j = g * GB + q;
             const cpx<float> zj = E[(j * zstep) & (M - 1)];                       // wave-uniform
-            yk[j] = spectral_bin(Xl[g & 1][q], Hl[g & 1][q], bin_w<R0>(w0, j), cmul(z0, zj), rho);
+            const cpx<float> wj = bin_w<R0>(w0, j);
+            yk[j] = spectral_bin(Xl[g & 1][q], Hl[g & 1][q], wj, cmul(z0, zj), rho);
+            if constexpr (LOG2H == 13) vo[j] = {yk[j].re * wj.re + yk[j].im * wj.im, yk[j].re * wj.im - yk[j].im * wj.re};
 #ifdef F2_STAMPS
             if (j == 0 || j == 7) {
                 asm volatile("s_nop 0" : "+v"(yk[j].re), "+v"(yk[j].im));
@@ -415,14 +418,8 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         // 2 + 3 (8192-point rows): both transforms' inputs formed at once - conj(A_e) / M and conj(A_o) / M =
         // conj(A) w_k / M - and their first passes run together (one set of derived twiddles); the odd transform's
         // first-pass outputs then wait in the registers Y' occupied, while the even transform goes through LDS
-        cpx<float> vo[PT];
 #pragma unroll
-        for (int j = 0; j < R0; ++j) {
-            const cpx<float> w = bin_w<R0>(w0, j);
-            const cpx<float> a = yk[j];
-            v[j] = {a.re, -a.im};
-            vo[j] = {a.re * w.re + a.im * w.im, a.re * w.im - a.im * w.re};
-        }
+        for (int j = 0; j < R0; ++j) v[j] = {yk[j].re, -yk[j].im};
         if (tid == 0) {
             v[0] = {0.5f * (yk[0].re + yk[0].im), 0.f};
             vo[0] = {0.5f * (yk[0].re - yk[0].im), 0.f};
