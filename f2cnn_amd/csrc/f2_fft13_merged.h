@@ -87,13 +87,14 @@ __device__ __forceinline__ void fft13_pass12_merged(cpx<float>* lds, const cpx<f
     __syncthreads();
 }
 
-// First pass of TWO 8192-point transforms of the same workgroup at once (the even-sample and the odd-sample transform
+// First pass of TWO transforms of the same workgroup at once (radix-16 first pass, one butterfly per thread: 4096-,
+// 8192- and 16384-point rows) (the even-sample and the odd-sample transform
 // of k_spectral_envelope): thread t runs butterfly t of both, so the fifteen twiddles it derives from two loaded ones
 // (f2_fft_lds.h, T0REGS) serve both - 52 instructions and two loads less per row and thread than two separate first
 // passes. The outputs stay in registers (v[brev<16>(k)] = output k); fft13_from_pass0 takes a transform from there.
-template <int NT, int PTV>
-__device__ __forceinline__ void fft13_pass0_pair(const cpx<float>* __restrict__ tw, int tid, cpx<float> (&va)[PTV], cpx<float> (&vb)[PTV]) {
-    constexpr int LOG2H = 13, R = 16, NB = (1 << LOG2H) / R;
+template <int LOG2H, int NT, int PTV>
+__device__ __forceinline__ void fft_pass0_pair(const cpx<float>* __restrict__ tw, int tid, cpx<float> (&va)[PTV], cpx<float> (&vb)[PTV]) {
+    constexpr int R = 16, NB = (1 << LOG2H) / R;
     static_assert(NT == NB && PTV == R && plan_bits(LOG2H, 0) == 4, "one radix-16 butterfly per thread");
     dft<R>(&va[0]);
     dft<R>(&vb[0]);
@@ -123,14 +124,27 @@ __device__ __forceinline__ void fft13_pass0_pair(const cpx<float>* __restrict__ 
 
 // the rest of an 8192-point transform whose first pass (fft13_pass0_pair) left its outputs in v: exchange, merged passes
 // 1 + 2, last pass; results in v as fft_regs_to_regs leaves them
-template <int PTV, int NT, bool T0REGS>
-__device__ __forceinline__ void fft13_from_pass0(cpx<float>* lds, const cpx<float>* __restrict__ tw, const cpx<float>* twl, int tid,
-                                                 cpx<float> (&v)[PTV]) {
+template <int LOG2H, int PTV, int NT, bool T0REGS, int PASS = 1>
+__device__ __forceinline__ void fft_remaining_passes(cpx<float>* lds, const cpx<float>* __restrict__ tw, const cpx<float>* twl, int tid,
+                                                     cpx<float> (&v)[PTV]) {
+    constexpr int NP = plan_npass(LOG2H);
+    if constexpr (PASS < NP) {
+        fft_pass<float, LOG2H, PASS, false, PASS == NP - 1, PTV, NT, false, T0REGS>(lds, tw, twl, tid, v);
+        fft_remaining_passes<LOG2H, PTV, NT, T0REGS, PASS + 1>(lds, tw, twl, tid, v);
+    }
+}
+template <int LOG2H, int PTV, int NT, bool T0REGS>
+__device__ __forceinline__ void fft_from_pass0(cpx<float>* lds, const cpx<float>* __restrict__ tw, const cpx<float>* twl, int tid,
+                                               cpx<float> (&v)[PTV]) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[cpad(tid * 16 + k)] = v[brev<16>(k)];     // pass 0 has stride 1: outputs 16 t + k
     __syncthreads();
-    fft13_pass12_merged<NT, PTV>(lds, twl, tid, v);
-    fft_pass<float, 13, 3, false, true, PTV, NT, false, T0REGS>(lds, tw, twl, tid, v);
+    if constexpr (LOG2H == 13) {
+        fft13_pass12_merged<NT, PTV>(lds, twl, tid, v);
+        fft_pass<float, 13, 3, false, true, PTV, NT, false, T0REGS>(lds, tw, twl, tid, v);
+    } else {
+        fft_remaining_passes<LOG2H, PTV, NT, T0REGS>(lds, tw, twl, tid, v);
+    }
 }
 
 // the whole 8192-point transform, registers (first-pass layout) to registers (as fft_regs_to_regs leaves them)

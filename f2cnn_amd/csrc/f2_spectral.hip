@@ -343,7 +343,9 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     static_assert(ITER0 == 1 && R0 == 16, "one radix-16 butterfly per thread in the first pass");
     constexpr int GB = F2_SPEC_GB, NG = R0 / GB;
     cpx<float> yk[PT], v[PT];
-    [[maybe_unused]] cpx<float> vo[PT];   // 8192-point rows: conj(A_o) / M, formed while the bin's phase factor is at hand
+    // rows whose first pass is one radix-16 butterfly per thread (all three length classes served): the two transforms share it
+    constexpr bool PAIRED = R0 == 16 && NB0 == NT && plan_npass(LOG2H) >= 3;
+    [[maybe_unused]] cpx<float> vo[PT];   // conj(A_o) / M, formed while the bin's phase factor is at hand
     const unsigned zstep = ((unsigned)NB0 * (unsigned)n) & (M - 1);
     cpx<float> w0 = E[tid];
     cpx<float> z0 = E[__umul24((unsigned)tid, (unsigned)n) & (M - 1)];
@@ -382,7 +384,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
             const cpx<float> zj = E[(j * zstep) & (M - 1)];                       // wave-uniform
             const cpx<float> wj = bin_w<R0>(w0, j);
             yk[j] = spectral_bin(Xl[g & 1][q], Hl[g & 1][q], wj, cmul(z0, zj), rho);
-            if constexpr (LOG2H == 13) vo[j] = {yk[j].re * wj.re + yk[j].im * wj.im, yk[j].re * wj.im - yk[j].im * wj.re};
+            if constexpr (PAIRED) vo[j] = {yk[j].re * wj.re + yk[j].im * wj.im, yk[j].re * wj.im - yk[j].im * wj.re};
 #ifdef F2_STAMPS
             if (j == 0 || j == 7) {
                 asm volatile("s_nop 0" : "+v"(yk[j].re), "+v"(yk[j].im));
@@ -414,8 +416,8 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     float er[NBLK], ei[NBLK];
     float pad_e, pad_o;
     constexpr bool T0R = derive_tw0<float, LOG2H>();
-    if constexpr (LOG2H == 13) {
-        // 2 + 3 (8192-point rows): both transforms' inputs formed at once - conj(A_e) / M and conj(A_o) / M =
+    if constexpr (PAIRED) {
+        // 2 + 3: both transforms' inputs formed at once - conj(A_e) / M and conj(A_o) / M =
         // conj(A) w_k / M - and their first passes run together (one set of derived twiddles); the odd transform's
         // first-pass outputs then wait in the registers Y' occupied, while the even transform goes through LDS
 #pragma unroll
@@ -427,15 +429,15 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         F2_SSTAMP(4);
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e), "+v"(v[0].re), "+v"(vo[PT - 1].im));
-        fft13_pass0_pair<NT, PT>(tw, tid_e, v, vo);
-        fft13_from_pass0<PT, NT, T0R>(lds, tw, twl, tid_e, v);
+        fft_pass0_pair<LOG2H, NT, PT>(tw, tid_e, v, vo);
+        fft_from_pass0<LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, v);
 #pragma unroll
         for (int j = 0; j < R0; ++j) {
             const cpx<float> a = v[brev<R0>(j)];
             er[j] = fsqrt(a.re * a.re + a.im * a.im);
         }
         pad_e = fabsf(v[brev<R0>(R0 - 1)].re);
-        fft13_from_pass0<PT, NT, T0R>(lds, tw, twl, tid_e, vo);
+        fft_from_pass0<LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, vo);
         F2_SSTAMP(5);
 #pragma unroll
         for (int j = 0; j < R0; ++j) {
