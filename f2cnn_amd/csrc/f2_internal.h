@@ -24,8 +24,8 @@ struct f2_spec_tables {
     int64_t tpitch = 0;
     f2_scratch hu, e, lgroup, e64;
 };
-#define F2_SPECTRAL_MIN_LOG2H 12   // rows of 4097 ... 32768 samples
-#define F2_SPECTRAL_MAX_LOG2H 14
+#define F2_SPECTRAL_MIN_LOG2H 12   // rows of 4097 ... 65536 samples
+#define F2_SPECTRAL_MAX_LOG2H 15
 
 struct f2_ctx {
     int device = 0;

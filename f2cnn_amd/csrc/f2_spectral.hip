@@ -77,6 +77,9 @@ typedef float f2_f4 __attribute__((ext_vector_type(4)));
 #ifndef F2_KS_CGROUP
 #define F2_KS_CGROUP 32
 #endif
+#ifndef F2_KS_CGROUP_LONG
+#define F2_KS_CGROUP_LONG 8     // long rows: one 512 KB channel table per XCD at a time
+#endif
 #ifndef F2_KS_STORE_AUX
 #define F2_KS_STORE_AUX 2    // raw buffer store cache policy bits: 0 default, 1 sc0, 2 nt, 16 sc1 (measured: nt 6.74, sc1 6.87, default 7.10 ms)
 #endif
@@ -84,6 +87,13 @@ typedef unsigned int f2_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int f2_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer(double* y, int n) {
     return __builtin_amdgcn_make_buffer_rsrc(y, 0, n * 8, 0x00020000);
+}
+// the same from values the compiler may have moved to vector registers (scalar-register pressure): made wave-uniform
+// again explicitly - a descriptor held in vector registers turns every buffer access into a readfirstlane loop
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer_uniform(double* y, int n) {
+    const unsigned long long a = (unsigned long long)y;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return row_buffer((double*)(((unsigned long long)hi << 32) | lo), __builtin_amdgcn_readfirstlane(n));
 }
 // envelope samples i0, i0 + 1 of a row of n samples
 __device__ __forceinline__ void store_row_pair_buf(__amdgpu_buffer_rsrc_t r, int n, int i0, double a, double b) {
@@ -140,10 +150,13 @@ constexpr size_t lowpass_tab_lds_bytes() {
 // Thread t holds the envelope pairs (2m, 2m+1), m = t + NT jj (er[jj], ei[jj]); y[n] = q y[n-1] + b0 (e[n] + e[n-1]) from
 // zero state; float64 rows out as coalesced 16-byte stores. lptab[t] = {q^(2 (lane+1)), q^(2 t), (q^2)^((lane & 15) + 1),
 // (q^2)^((lane & 31) + 1)}. All threads call it, after a barrier that makes `smem` free.
-template <int NT, int NBLK>
+// CHAINED (rows longer than one sweep of the workgroup, k_spectral_envelope_long): the pairs are those of the samples from
+// `ibase` on, e_in = e[ibase - 1], *ychain = y[ibase - 1] on entry and y[ibase + 2 NT NBLK - 1] on return.
+template <int NT, int NBLK, bool CHAINED = false>
 __device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK], const float (&ei)[NBLK], const LowpassConsts& K,
                                                         const f2_f4* __restrict__ lptab, unsigned char* smem,
-                                                        double* __restrict__ y, int n, int tid) {
+                                                        double* __restrict__ y, int n, int tid, int ibase = 0, float e_in = 0.f,
+                                                        double* ychain = nullptr) {
     static_assert(NBLK == 16, "sixteen blocks: one DPP row chains them");
     constexpr int NW = NT / 64;
     float* e1s = reinterpret_cast<float*>(smem);   // [NBLK][NT] odd samples, for e[n-1]
@@ -151,7 +164,6 @@ __device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK],
     float* cwl = wtot + NBLK * NW;                 // [NBLK][NW] zero-state value of the block entering each wave
     float* ycar = cwl + NBLK * NW;                 // [NBLK] true y entering each block
     const int lane = tid & 63, wv = tid >> 6;
-    const __amdgpu_buffer_rsrc_t yb = row_buffer(y, n);
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) e1s[jj * NT + tid] = ei[jj];
     const f2_f4 tc = lptab[tid];
@@ -159,7 +171,7 @@ __device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK],
     float u0[NBLK], u1[NBLK], sc[NBLK];
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) {
-        const float eprev = tid > 0 ? e1s[jj * NT + tid - 1] : (jj > 0 ? e1s[(jj - 1) * NT + NT - 1] : 0.f);
+        const float eprev = tid > 0 ? e1s[jj * NT + tid - 1] : (jj > 0 ? e1s[(jj - 1) * NT + NT - 1] : (CHAINED ? e_in : 0.f));
         u0[jj] = K.b0f * (er[jj] + eprev);
         u1[jj] = K.b0f * (ei[jj] + er[jj]);
         sc[jj] = fmaf(K.qf, u0[jj], u1[jj]);
@@ -193,13 +205,25 @@ __device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK],
             c = fma(K.gw, c, (double)wtot[tid * NW + w2]);
         }
         const double G1 = K.gblk, G2 = G1 * G1, G4 = G2 * G2, G8 = G4 * G4;
+        double yin = 0.0;
+        if constexpr (CHAINED) {
+            yin = *ychain;
+            if (tid == 0) c = fma(G1, yin, c);       // the state entering block 0 decays through it
+        }
         c = fma(G1, dpp_mov<0x111, 0xF>(c), c);
         c = fma(G2, dpp_mov<0x112, 0xF>(c), c);
         c = fma(G4, dpp_mov<0x114, 0xF>(c), c);
         c = fma(G8, dpp_mov<0x118, 0xF>(c), c);
-        ycar[tid] = (float)dpp_mov<0x111, 0xF>(c);   // (lane 0 reads 0)
+        const double cprev = dpp_mov<0x111, 0xF>(c);   // (lane 0 reads 0)
+        if constexpr (CHAINED) {
+            ycar[tid] = tid == 0 ? (float)yin : (float)cprev;
+            if (tid == NBLK - 1) *ychain = c;        // (same wave as the reads of *ychain above: program order)
+        } else {
+            ycar[tid] = (float)cprev;
+        }
     }
     __syncthreads();
+    const __amdgpu_buffer_rsrc_t yb = CHAINED ? row_buffer_uniform(y, n) : row_buffer(y, n);
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) {
         const float cw = cwl[jj * NW + wv];
@@ -208,7 +232,7 @@ __device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK],
         const float sprev = lane > 0 ? up : cw;                // ... at the end of the previous pair
         const float y0 = fmaf(K.qf, fmaf(tc.y, ycar[jj], sprev), u0[jj]);
         const float y1 = fmaf(K.qf, y0, u1[jj]);
-        store_row_pair_buf(yb, n, 2 * (tid + NT * jj), (double)y0, (double)y1);
+        store_row_pair_buf(yb, n, ibase + 2 * (tid + NT * jj), (double)y0, (double)y1);
     }
 }
 
@@ -344,8 +368,8 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     constexpr int GB = F2_SPEC_GB, NG = R0 / GB;
     cpx<float> yk[PT], v[PT];
     // rows whose first pass is one radix-16 butterfly per thread (all three length classes served): the two transforms share it
-    constexpr bool PAIRED = R0 == 16 && NB0 == NT && plan_npass(LOG2H) >= 3;
-    [[maybe_unused]] cpx<float> vo[PT];   // conj(A_o) / M, formed while the bin's phase factor is at hand
+    static_assert(NB0 == NT && plan_npass(LOG2H) >= 3, "fft_pass0_pair + fft_from_pass0");
+    cpx<float> vo[PT];   // conj(A_o) / M = conj(A) w_k / M, formed while the bin's phase factor is at hand
     const unsigned zstep = ((unsigned)NB0 * (unsigned)n) & (M - 1);
     cpx<float> w0 = E[tid];
     cpx<float> z0 = E[__umul24((unsigned)tid, (unsigned)n) & (M - 1)];
@@ -384,7 +408,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
             const cpx<float> zj = E[(j * zstep) & (M - 1)];                       // wave-uniform
             const cpx<float> wj = bin_w<R0>(w0, j);
             yk[j] = spectral_bin(Xl[g & 1][q], Hl[g & 1][q], wj, cmul(z0, zj), rho);
-            if constexpr (PAIRED) vo[j] = {yk[j].re * wj.re + yk[j].im * wj.im, yk[j].re * wj.im - yk[j].im * wj.re};
+            vo[j] = {yk[j].re * wj.re + yk[j].im * wj.im, yk[j].re * wj.im - yk[j].im * wj.re};
 #ifdef F2_STAMPS
             if (j == 0 || j == 7) {
                 asm volatile("s_nop 0" : "+v"(yk[j].re), "+v"(yk[j].im));
@@ -416,7 +440,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     float er[NBLK], ei[NBLK];
     float pad_e, pad_o;
     constexpr bool T0R = derive_tw0<float, LOG2H>();
-    if constexpr (PAIRED) {
+    {
         // 2 + 3: both transforms' inputs formed at once - conj(A_e) / M and conj(A_o) / M =
         // conj(A) w_k / M - and their first passes run together (one set of derived twiddles); the odd transform's
         // first-pass outputs then wait in the registers Y' occupied, while the even transform goes through LDS
@@ -445,46 +469,6 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
             ei[j] = fsqrt(a.re * a.re + a.im * a.im);
         }
         pad_o = fabsf(vo[brev<R0>(R0 - 1)].re);
-    } else {
-    // 2. even samples: conj(a[2m]) = DFT_H(conj(A_e) / M)
-#pragma unroll
-    for (int q = 0; q < PT; ++q) v[q] = {yk[q].re, -yk[q].im};
-    if (tid == 0) v[0] = {0.5f * (yk[0].re + yk[0].im), 0.f};
-    // (the thread index each transform works from is tied to its input: the first-pass twiddles - 30 registers once
-    // derived - and the LDS addresses are then not formed while the previous phase still needs the registers)
-    int tid_e = tid;
-    asm volatile("" : "+v"(tid_e), "+v"(v[0].re), "+v"(v[PT - 1].im));
-    if constexpr (LOG2H == 13) fft13_regs_to_regs<PT, NT, T0R>(lds, tw, twl, tid_e, v);
-    else fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, v);
-    // the last pass left sample m = tid + j NB0 in v[brev(j)]
-#pragma unroll
-    for (int j = 0; j < R0; ++j) {
-        const cpx<float> a = v[brev<R0>(j)];
-        er[j] = fsqrt(a.re * a.re + a.im * a.im);
-    }
-    pad_e = fabsf(v[brev<R0>(R0 - 1)].re);   // |Re a| of the last block's even sample
-    // 3. odd samples: conj(a[2m+1]) = DFT_H(conj(A_o) / M), conj(A_o(k)) = conj(A(k)) w_k  (w_k formed again from
-    //    w_tid: kept across the first transform they would cost 30 registers)
-    asm volatile("" : "+v"(w0.re), "+v"(w0.im));
-#pragma unroll
-    for (int j = 0; j < R0; ++j) {
-        const cpx<float> w = bin_w<R0>(w0, j);
-        const cpx<float> a = yk[j];
-        v[j] = {a.re * w.re + a.im * w.im, a.re * w.im - a.im * w.re};
-    }
-    if (tid == 0) v[0] = {0.5f * (yk[0].re - yk[0].im), 0.f};
-    F2_SSTAMP(4);
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o), "+v"(v[0].re), "+v"(v[PT - 1].im));
-    if constexpr (LOG2H == 13) fft13_regs_to_regs<PT, NT, T0R>(lds, tw, twl, tid_o, v);
-    else fft_regs_to_regs<float, LOG2H, PT, NT, T0R>(lds, tw, twl, tid_o, v);
-    F2_SSTAMP(5);
-#pragma unroll
-    for (int j = 0; j < R0; ++j) {
-        const cpx<float> a = v[brev<R0>(j)];
-        ei[j] = fsqrt(a.re * a.re + a.im * a.im);
-    }
-    pad_o = fabsf(v[brev<R0>(R0 - 1)].re);
     }
     // 4. accuracy guard: block jj of this thread is the sample pair 2 (tid + NT jj), + 1. Inside [0, n) the row's
     //    maximum; in the padding region the REAL part of a (the zero-padded row itself: zero in exact arithmetic, while
@@ -532,10 +516,214 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
 #endif
 }
 
-// (Rows of 32769..65536 samples - four 16384-point sub-transforms per row from a spectrum parked in the row's output slot,
-// quad low-pass - were built and verified in round 3 and taken out again: with 4 x 16 magnitudes to keep next to the
-// transform's 64 + 32 registers the 1024-thread workgroup spilled 150 registers and ran at 195 us per row against ~100 us for
-// the filterbank kernel + on-chip pair kernel it was to replace. DESIGN.md section 7.)
+// ---- rows of 32769 .. 65472 samples: M = 65536, H = 32768 ----
+// The two H-point transforms of such a row (131072 + 131072 bytes as float32) do not fit the LDS of a CU. Decimating
+// the output once more, a[4 m + r] = IDFT_Q(B_r)[m], Q = H / 2 = 16384, r = 0..3, with the folded one-sided spectrum
+//     conj B_r(k) = w_k^r [ conj A'(k) + (-i)^r conj A'(k + Q) ],   k < Q,   A' = A / M  (k = 0 also takes (-1)^r A'(H)),
+// gives four 16384-point transforms per row, run as two passes of the pair (r, r + 2) = (p, p + 2): the pair shares
+// P = conj A'(k), R = (-i)^p conj A'(k + Q) (v = w^p (P + R), vo = w^(p+2) (P - R)) and its first transform pass, exactly
+// like the even / odd pair of the shorter rows - the spectrum bins are formed twice per row (once per pass) instead of
+// being kept (32 bins = 64 registers per thread). The 4 x 16 magnitudes per thread cannot wait in registers for the
+// low-pass either (a first version that kept them spilled 150 registers and ran at 195 us per row): every pass parks
+// its magnitudes as float32 in the upper half of the row's own output slot (bytes 4 n + 4 i of the 8 n: sample i of
+// the envelope lands at byte 8 i, so the two sweeps of the low-pass below - samples [0, 32768) and [32768, n) - each read
+// their parked inputs before any of their outputs could overwrite them, barriers in between; the parked lines stay in
+// L2 / the Infinity Cache: 4 bytes written + read per sample next to the 8 stored).
+// Parking layout (float index inside the row's 2 n floats): two banks - samples below / from 32768, i.e. the inputs of
+// the first / second low-pass sweep - at n and n + 32768; inside a bank one plane per r (a transform's outputs are then
+// stored as whole 256-byte runs per wave instead of one float every 16 bytes), plane sizes summing to the bank's samples.
+// Guard, flags, row order and arguments as k_spectral_envelope; `tw` = the tables of the 16384-point transform.
+#ifndef F2_KSL_PARK_AUX
+#define F2_KSL_PARK_AUX 0    // cache policy of the parked magnitudes (stores and loads)
+#endif
+// float index of plane r of bank `bank` (m counted from the bank's first sample)
+__device__ __forceinline__ int park_plane(int n, int bank, int r) {
+    constexpr int MB = 8192;                      // m of the first sample of bank 1
+    if (bank == 0) return n + r * MB;
+    const int nb = n - 4 * MB;                    // samples in bank 1; planes q = 0..r-1 hold ceil((nb - q) / 4) each
+    const int before = r == 0 ? 0 : r == 1 ? (nb + 3) >> 2 : r == 2 ? ((nb + 3) >> 2) + ((nb + 2) >> 2) : nb - (nb >> 2);
+    return n + 4 * MB + before;
+}
+__global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
+    SpecParams P, const cpx<float>* __restrict__ Xall, const f2_f4* __restrict__ HUall, const cpx<float>* __restrict__ E,
+    const float* __restrict__ rho_all, const int64_t* __restrict__ offsets, const int* __restrict__ ulist,
+    const f2_f4* __restrict__ lptab, const cpx<float>* __restrict__ tw) {
+    constexpr int LOG2Q = 14, NT = 1024, Q = 1 << LOG2Q, H = 2 * Q, M = 2 * H;
+    static_assert(threads_for<float, LOG2Q>() == NT, "the 16-16-4-16 plan on 1024 threads");
+    constexpr int CS = cpad_size(Q);
+    constexpr int R0 = 16, NB0 = Q / R0, PT = 16, NBLK = 16;
+    static_assert(NB0 == NT && plan_points_per_thread(LOG2Q, NT) == PT, "one radix-16 butterfly per thread in the first pass");
+    constexpr size_t LP = lowpass_tab_lds_bytes<NT, NBLK>();
+    constexpr int LDS_BYTES = (int)((size_t)CS * 8 > LP ? (size_t)CS * 8 : LP);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    constexpr int TWL = plan_tw_lds_count(LOG2Q);
+    __shared__ __attribute__((aligned(16))) cpx<float> twl[TWL];
+    __shared__ unsigned guard[2];
+    __shared__ double ychain;
+    cpx<float>* lds = reinterpret_cast<cpx<float>*>(smem);
+
+    const int tid = threadIdx.x;
+    int u, c;
+    {
+        constexpr int CG = F2_KS_CGROUP_LONG;
+        const int nfull = P.C / CG, per = P.nutt * CG;
+        const int cg = min((int)(blockIdx.x / per), nfull);
+        const int rr = blockIdx.x - cg * per;
+        const int gsz = cg < nfull ? CG : P.C - nfull * CG;
+        u = rr / gsz;
+        c = cg * CG + (rr - u * gsz);
+    }
+    const int row_id = u * P.C + c;
+    const int b = ulist[u];
+    const int64_t off = offsets[b];
+    const int n = (int)(offsets[b + 1] - off);
+    double* __restrict__ y = P.env + ((size_t)P.C * (size_t)off + (size_t)c * (size_t)n);
+    const float* __restrict__ rho = rho_all + (size_t)row_id * 8;
+    const cpx<float>* __restrict__ Xu = Xall + (size_t)u * P.xpitch;
+    const f2_f4* __restrict__ HUc = HUall + (size_t)c * P.tpitch;
+
+    for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2Q, 1) + i];
+    if (tid < 2) guard[tid] = 0u;
+    if (tid == 0) ychain = 0.0;
+
+    const unsigned zstep = ((unsigned)NB0 * (unsigned)n) & (M - 1);
+    cpx<float> w0 = E[tid];
+    cpx<float> z0 = E[((unsigned)tid * (unsigned)n) & (M - 1)];
+    const cpx<float> zq = E[((unsigned)Q * (unsigned)n) & (M - 1)];   // w_Q^n = (-i)^n
+    float yh = 0.f;   // Y'(H) (real)
+    if (tid == 0) yh = spectral_bin(Xu[H], HUc[H], cpx<float>{-1.f, 0.f}, cpx<float>{(n & 1) ? -1.f : 1.f, 0.f}, rho).re;
+    constexpr bool T0R = derive_tw0<float, LOG2Q>();
+    float gin = 0.f, gout = 0.f;
+    unsigned kb = (unsigned)tid;
+#ifdef F2_STAMPS
+    unsigned long long sst[8] = {0};
+#endif
+    F2_SSTAMP(0);
+#pragma unroll 1
+    for (int p = 0; p < 2; ++p) {
+        cpx<float> v[PT], vo[PT];
+        constexpr int GB = 4;
+#pragma unroll
+        for (int g = 0; g < R0 / GB; ++g) {
+            cpx<float> Xl[2][GB];
+            f2_f4 Hl[2][GB];
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+                Xl[0][q] = F2_KS_LOADX(Xu + (g * GB + q) * NB0, kb);
+                Hl[0][q] = F2_KS_LOADH(HUc + (g * GB + q) * NB0, kb);
+                Xl[1][q] = F2_KS_LOADX(Xu + Q + (g * GB + q) * NB0, kb);
+                Hl[1][q] = F2_KS_LOADH(HUc + Q + (g * GB + q) * NB0, kb);
+            }
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+                const int j = g * GB + q;
+                const cpx<float> w = cmul(w0, E[j * NB0]);                       // w_k, k = tid + j NB0 (wave-uniform factor)
+                const cpx<float> z = cmul(z0, E[(j * zstep) & (M - 1)]);          // w_k^n
+                const cpx<float> ya = spectral_bin(Xl[0][q], Hl[0][q], w, z, rho);
+                const cpx<float> yb2 = spectral_bin(Xl[1][q], Hl[1][q], cpx<float>{w.im, -w.re}, cmul(z, zq), rho);   // bin k + Q
+                cpx<float> cp = {ya.re, -ya.im};
+                if (j == 0 && tid == 0) cp = {0.5f * (ya.re + (p ? -yh : yh)), 0.f};
+                const cpx<float> cr = p ? cpx<float>{-yb2.im, -yb2.re} : cpx<float>{yb2.re, -yb2.im};   // (-i)^p conj
+                const cpx<float> sm = cp + cr, df = cp - cr;
+                const cpx<float> w2 = cmul(w, w);
+                v[j] = p ? cmul(sm, w) : sm;
+                vo[j] = cmul(df, p ? cmul(w2, w) : w2);
+            }
+            // the next group's loads are not issued before this group has been consumed (registers)
+            asm volatile("" : "+v"(kb), "+v"(w0.re), "+v"(w0.im), "+v"(z0.re), "+v"(z0.im), "+v"(v[g * GB].re), "+v"(vo[g * GB + GB - 1].im));
+        }
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e), "+v"(v[0].re), "+v"(vo[PT - 1].im));
+#ifdef F2_STAMPS
+        if (p == 0) F2_SSTAMP(1);
+        else F2_SSTAMP(3);
+#endif
+        fft_pass0_pair<LOG2Q, NT, PT>(tw, tid_e, v, vo);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // conj a[4 m + r], m = tid + j NT in (half ? vo : v)[brev(j)], r = p + 2 half
+            if (half == 0) fft_from_pass0<LOG2Q, PT, NT, T0R>(lds, tw, twl, tid_e, v);
+            else fft_from_pass0<LOG2Q, PT, NT, T0R>(lds, tw, twl, tid_e, vo);
+            const int r = p + 2 * half;
+            const __amdgpu_buffer_rsrc_t yb = row_buffer_uniform(y, n);
+            // (one lane offset per bank; the block j adds a compile-time 4096 bytes)
+            const int pv0 = 4 * (park_plane(n, 0, r) + tid), pv1 = 4 * (park_plane(n, 1, r) + tid);
+#pragma unroll
+            for (int j = 0; j < R0; ++j) {
+                const cpx<float> a = half ? vo[brev<R0>(j)] : v[brev<R0>(j)];
+                const float e = fsqrt(a.re * a.re + a.im * a.im);
+                const bool in = 4 * (tid + NT * j) + r < n;
+                // (no branch per sample: a sample beyond the row goes to an offset the buffer's range check drops)
+#ifndef F2_KSL_KO_PARK   // knock-out (timing only)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e), yb, in ? (j < 8 ? pv0 : pv1) : 0x7ffffff0, 4 * NT * (j & 7),
+                                                      F2_KSL_PARK_AUX);
+#endif
+                gin = fmaxf(gin, in ? e : 0.f);
+                if (j == R0 - 1) gout = fmaxf(gout, in ? 0.f : fabsf(a.re));
+            }
+        }
+#ifdef F2_STAMPS
+        if (p == 0) F2_SSTAMP(2);
+        else F2_SSTAMP(4);
+#endif
+    }
+    gin = wave_max63(gin);
+    gout = wave_max63(gout);
+    if ((tid & 63) == 63) {
+        atomicMax(&guard[0], __float_as_uint(gin));
+        atomicMax(&guard[1], __float_as_uint(gout));
+    }
+    // the parked magnitudes are read back by other threads of the same workgroup (same CU, same L1): workgroup scope -
+    // an agent-scope fence writes the XCD's whole L2 back (measured: 8 x the kernel time)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // low-pass + stores: two sweeps of 2 NT NBLK = 32768 samples in the pair layout of lowpass_pairs_store_tab
+    // (loading the parked inputs of both sweeps up front costs 90 spilled registers next to the low-pass's own 80)
+#ifdef F2_KSL_KO_SWEEP   // knock-out (timing only)
+    if (n < 0)
+#endif
+#pragma unroll 1
+    for (int sw = 0; sw < 2; ++sw) {
+        const int ibase = sw * 2 * NT * NBLK;
+        const __amdgpu_buffer_rsrc_t yb = row_buffer_uniform(y, n);
+        float er[NBLK], ei[NBLK];
+        // samples i0 = ibase + 2 (tid + NT jj) = 4 m + r and i0 + 1, r = 0 or 2: the same m of two neighbouring planes of bank sw
+        const int rl = 2 * (tid & 1);
+        const int pva = 4 * (park_plane(n, sw, rl) + (tid >> 1)), pvb = 4 * (park_plane(n, sw, rl + 1) + (tid >> 1));
+#pragma unroll
+        for (int jj = 0; jj < NBLK; ++jj) {
+            const int i0 = ibase + 2 * (tid + NT * jj);
+            // (samples beyond the row: an out-of-range offset, which reads as 0)
+            er[jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yb, i0 < n ? pva : 0x7ffffff0, 2 * NT * jj, F2_KSL_PARK_AUX));
+            ei[jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yb, i0 + 1 < n ? pvb : 0x7ffffff0, 2 * NT * jj, F2_KSL_PARK_AUX));
+        }
+        if (!P.lpf) {
+            __syncthreads();   // every load of the sweep before any of its stores
+#pragma unroll
+            for (int jj = 0; jj < NBLK; ++jj) store_row_pair_buf(yb, n, ibase + 2 * (tid + NT * jj), (double)er[jj], (double)ei[jj]);
+        } else {
+            const float e_in =   // sample 32767: the last of plane 3 of bank 0
+                sw ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yb, 4 * (park_plane(n, 0, 3) + 8191), 0, F2_KSL_PARK_AUX)) : 0.f;
+            lowpass_pairs_store_tab<NT, NBLK, true>(er, ei, P.lp, lptab, smem, y, n, tid, ibase, e_in, &ychain);
+        }
+        __syncthreads();   // (the second sweep's inputs were parked before the first barrier above; `smem` is free again)
+#ifdef F2_STAMPS
+        if (sw == 0) F2_SSTAMP(5);
+        else F2_SSTAMP(6);
+#endif
+    }
+    if (tid == 0) {
+        const float gi = __uint_as_float(guard[0]), go = __uint_as_float(guard[1]);
+        if (go > P.tol * gi) P.uflag[b] = 1;
+    }
+#ifdef F2_STAMPS
+    F2_SSTAMP(7);
+    if (tid == 0 && P.stamps)
+        for (int k = 0; k < 8; ++k) P.stamps[(size_t)blockIdx.x * 8 + k] = sst[k];
+#endif
+}
+
 // ---- X = DFT_M(x zero-padded), k = 0..H, float64 arithmetic, float32 out ----
 // (float64: the float32 rounding of a transform is relative to the LOUDEST band of the utterance; a channel that sits
 // 60 dB below it - speech above 4 kHz - would inherit 1e-4 of its own level.)
@@ -938,7 +1126,7 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
     F2_TRY(spectral_tables(ctx, C, LOG2H, &tab));
     // float64 transform of the utterances: 2^13 packed complex points fit in LDS; longer rows are decimated in time
     constexpr int LOGD = LOG2H > 13 ? LOG2H - 13 : 0, LOG2HS = LOG2H - LOGD;
-    constexpr int FFTLOG = LOG2H;
+    constexpr int FFTLOG = LOG2H == 15 ? 14 : LOG2H;   // rows of the longest class: four 16384-point transforms each
     F2_TRY(ensure_twiddles<double>(ctx, LOG2HS, ctx->tw_sp[1][LOG2HS]));
     F2_TRY(ensure_twiddles<float>(ctx, FFTLOG, ctx->tw_sp[0][FFTLOG]));
     const int64_t xpitch = H + 8;
@@ -985,9 +1173,14 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
     if (nstamp <= (size_t)8 * 128 * 2048) P.stamps = d_stamps;
 #endif
     F2_TRY(f2_prof_begin(ctx, F2_K_FUSED));
-    hipLaunchKernelGGL((k_spectral_envelope<FFTLOG>), dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, FFTLOG>()), 0,
-                       ctx->stream, P, (const cpx<float>*)d_X, (const f2_f4*)tab->hu.ptr, (const cpx<float>*)tab->e.ptr,
-                       (const float*)d_rho, d_offsets, d_ulist, d_lptab, (const cpx<float>*)ctx->tw_sp[0][FFTLOG].ptr);
+    if constexpr (LOG2H == 15)
+        hipLaunchKernelGGL(k_spectral_envelope_long, dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, FFTLOG>()), 0,
+                           ctx->stream, P, (const cpx<float>*)d_X, (const f2_f4*)tab->hu.ptr, (const cpx<float>*)tab->e.ptr,
+                           (const float*)d_rho, d_offsets, d_ulist, d_lptab, (const cpx<float>*)ctx->tw_sp[0][FFTLOG].ptr);
+    else
+        hipLaunchKernelGGL((k_spectral_envelope<FFTLOG>), dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, FFTLOG>()), 0,
+                           ctx->stream, P, (const cpx<float>*)d_X, (const f2_f4*)tab->hu.ptr, (const cpx<float>*)tab->e.ptr,
+                           (const float*)d_rho, d_offsets, d_ulist, d_lptab, (const cpx<float>*)ctx->tw_sp[0][FFTLOG].ptr);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_FUSED));
 #ifdef F2_STAMPS
@@ -1005,7 +1198,9 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
             t1 = std::max(t1, h[r * 8 + 7]);
             life += (double)(h[r * 8 + 7] - h[r * 8]);
         }
-        static const char* names[8] = {"", "bin 0 ready", "bin 7 ready", "bin 15 ready", "fft even+mag+odd input", "fft odd", "mag+guard", "lpf+stores"};
+        static const char* names_s[8] = {"", "bin 0 ready", "bin 7 ready", "bin 15 ready", "transform inputs", "both transforms + even magnitudes", "odd magnitudes + guard", "lpf+stores"};
+        static const char* names_l[8] = {"", "spectrum r=0,2", "transforms r=0,2 + parking", "spectrum r=1,3", "transforms r=1,3 + parking", "low-pass sweep 0", "low-pass sweep 1", "flag"};
+        const char* const* names = LOG2H == 15 ? names_l : names_s;
         fprintf(stderr, "[stamps KS] mean ticks (10 ns) per workgroup:");
         for (int k = 1; k < 8; ++k) fprintf(stderr, " %s=%.0f", names[k], acc[k] / rows);
         fprintf(stderr, "\n[stamps KS] mean workgroup lifetime %.1f ticks, kernel span %.0f ticks, workgroups alive at once %.1f\n",
@@ -1038,6 +1233,7 @@ int f2_launch_spectral(f2_ctx* ctx, const void* d_wave, int wave_dtype, const in
         F2_SPEC_CASE(12)
         F2_SPEC_CASE(13)
         F2_SPEC_CASE(14)
+        F2_SPEC_CASE(15)
         default:
             return f2_fail(ctx, F2_ERR_UNSUPPORTED, "spectral path: length class 2^%d not built", log2h + 1);
     }

@@ -32,13 +32,14 @@ def fused(ctx, waves, coefs, lpf, cutoff=50.0, **opts):
 
 @pytest.mark.parametrize("lpf", [False, True])
 def test_ragged_batch_against_oracle_and_two_kernel_route(lpf):
-    """Lengths on the three length classes the kernel serves (4097..8192, 8193..16384, 16385..32768 samples: the last one
-    transforms its utterances decimated by two), odd lengths, the shortest padding it accepts (64 samples), and lengths
-    it leaves to the two-kernel route (fewer padding samples, short and long rows) in one batch; 128 channels."""
+    """Lengths on the four length classes the kernels serve (4097..8192, 8193..16384, 16385..32768 samples: the last one
+    transforms its utterances decimated by two; 32769..65472: four 16384-point transforms per row, utterances decimated
+    by four), odd lengths, the shortest padding they accept (64 samples), and lengths they leave to the two-kernel route
+    (fewer padding samples, short and longer rows) in one batch; 128 channels."""
     ctx = _lib.default_context()
     coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
     lens = [16000, 15999, 9000, 8193, 16320, 16321, 4097, 5000, 8128, 8129, 300, 16384, 20000, 1, 32704, 32705, 16385,
-            27001, 40000, 32769]
+            27001, 40000, 32769, 65472, 65473, 50001, 65536, 33333, 70000]
     waves = [orc.synth_utterance(500 + i, n) for i, n in enumerate(lens)]
     got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
     old, _ = fused(ctx, waves, coefs, lpf, spectral=0)
@@ -91,10 +92,12 @@ def test_accuracy_guard_sends_a_late_click_back():
     click[15990] = 32767
     click2 = np.zeros(30000, np.int16)          # the same in the 16385..32768-sample class
     click2[29995] = 32767
-    waves = [orc.synth_utterance(1, 16000), click, orc.synth_utterance(2, 12000), click2, orc.synth_utterance(3, 50001)]
+    click3 = np.zeros(50000, np.int16)          # and in the 32769..65472-sample class
+    click3[49996] = 32767
+    waves = [orc.synth_utterance(1, 16000), click, orc.synth_utterance(2, 12000), click2, orc.synth_utterance(3, 50001), click3]
     for lpf in (False, True):
         got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
-        assert flagged == 2
+        assert flagged == 3
         for w, g in zip(waves, got):
             assert chan_relerr(g, orc.filter_and_envelope(w, coefs, lpf, 50)) <= TOL
     # with the guard disabled the click really is out of tolerance on the spectral path (the guard is not idle)

@@ -8,7 +8,7 @@ build.LIB_PATH = os.path.abspath(os.environ.get("F2CNN_PROBE_LIB", "/root/repo/t
 from f2cnn_amd import _lib
 from f2cnn_amd.gammatone import filters
 import bench
-B, C, N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, 128, 16000
+B, C, N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, 128, int(sys.argv[4]) if len(sys.argv) > 4 else 16000
 lpf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = _lib.Context(0)
 ctx.set_option("spectral", int(sys.argv[3]) if len(sys.argv) > 3 else 1)   # 0: stamps of the filterbank kernel + envelope kernel route
