@@ -3,7 +3,7 @@
 // never exists - neither in HBM nor on chip. Same results as K1 -> K2 (reference: gammatone/filters.py:195-239
 // erb_filterbank followed by scripts/processing/EnvelopeExtraction.py:20-67) within the float32-FFT tolerance.
 //
-// Mathematics (prototype with the derivation checked against the oracle: tools/proto_spectral.py).  Row = channel c of
+// Mathematics (prototype with the derivation checked against the oracle: tests/diag/proto_spectral.py).  Row = channel c of
 // an utterance of n samples, M = 2^ceil(log2 n), H = M/2, z_k = exp(2 pi i k / M), w = 1/z_k.  The cascade of the four
 // second-order sections  D(w) y_m = N_m(w) y_(m-1),  D = 1 + a1 w + a2 w^2,  N_m = 1 + c_m w  (make_erb_filters: shared
 // poles, no w^2 term in the numerators; overall factor s = (A0/B0)^4 / gain) holds for the samples n' < n; for the

@@ -16,7 +16,7 @@ without cancellation.  The last outputs of the sections only depend on the last 
 The analytic signal of the one-sided spectrum splits into the even and the odd output samples: two H = M/2 point
 complex transforms, A_e(k) = A(k), A_o(k) = A(k) exp(i pi k / H)  (k = 0 takes the Nyquist term +-A(H)).
 
-Run:  python tools/proto_spectral.py   (CPU only; float32 emulation of the device arithmetic)
+Run:  python tests/diag/proto_spectral.py   (CPU only; float32 emulation of the device arithmetic)
 """
 import sys
 import numpy as np

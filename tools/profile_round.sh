@@ -23,6 +23,10 @@ python3 tools/pmc_summary.py $out/pmc_sq1 $out/pmc_sq2 > $out/pmc_sq_summary.txt
 python3 tools/make_traffic_json.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/traffic_cfg3.json > /dev/null
 find $out/kt_cfg3 -name "*kernel_stats.csv" -exec cp {} $out/bench_cfg3_kernel_stats.csv \;
 find $out/kt_cfg4 -name "*kernel_stats.csv" -exec cp {} $out/bench_cfg4_kernel_stats.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_cfg5r -- python3 bench.py --workload cfg5r --steps 2 --warmup 1 --corpus 5000 --no-cpu-baseline > $out/bench_cfg5r_line.json 2> $out/kt_cfg5r.err
+find $out/kt_cfg5r -name "*kernel_stats.csv" -exec cp {} $out/bench_cfg5r_kernel_stats.csv \;
+echo "cfg5r trace done"
+python3 tools/len_sweep.py 4000000 8000 16000 24000 32000 40000 48000 65000 65536 80000 131072 > $out/len_sweep.txt 2>&1
 F2CNN_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --corpus 2000 > $out/bench_2rank_one_device_line.json 2> $out/bench_2rank.err
 ./tools/ubench/fma64_operands > $out/ubench_fma64.txt 2>&1 || true
 echo "all done"
