@@ -571,7 +571,7 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
         d_gfb = gfb_or_null ? (double*)ctx->stage_aux.ptr : nullptr;
     }
     // Spectral path (f2_spectral.hip): utterances it can serve (float FFT, no GFB output wanted, make_erb_filters-shaped
-    // table, 4097..16384 samples with padding to look at) get their envelopes from ONE kernel that never materialises
+    // table, 4097..65472 samples with padding to look at) get their envelopes from ONE kernel that never materialises
     // the filterbank rows. Everything else - and any utterance that kernel's accuracy guard flags on the device - goes
     // through the filterbank kernel + envelope kernel below, which skip utterances whose flag is 0.
     const int* d_uflag = nullptr;
