@@ -211,6 +211,7 @@ const opt_entry kOptions[] = {
     {"k1_qwaves", &f2_ctx::opt_k1_qwaves, nullptr, 0, 1 << 20},
     {"env_pair", &f2_ctx::opt_env_pair, nullptr, 0, 1},
     {"env_plan4", &f2_ctx::opt_env_plan4, nullptr, 0, 1},
+    {"cnn_bf16x3", &f2_ctx::opt_cnn_bf16x3, nullptr, 0, 1},
 };
 const opt_entry* find_option(const char* key) {
     if (!key) return nullptr;

@@ -25,6 +25,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C1 = 32, C2 = 32, C3 = 64, C4 = 64, D1 = 516, D2 = 2;
 constexpr int PW = 34;  // patch width: 32 output columns + 2
@@ -441,6 +443,319 @@ __global__ __launch_bounds__(256) void k_conv34_mfma(const float* __restrict__ i
     }
 }
 
+// ---- the same kernel on the bf16 matrix cores, operands split in two bf16 pieces (option "cnn_bf16x3") ----
+// v_mfma_f32_32x32x16_bf16 runs at 16 x the rate of v_mfma_f32_32x32x2_f32. With a = a1 + a2, a1 = bf16(a), a2 = bf16(a - a1)
+// (round to nearest even, v_cvt_pk_bf16_f32) and the same for the weights, a1 b1 + a1 b2 + a2 b1 - three MFMAs with float32
+// accumulation, 5.3 x the f32 matrix rate - carries the product to ~2^-16 per term; on the cfg4 windows that moves the
+// scores by < 1e-6 and no label outside a float64-referee tie (tests/diag/bf16_split_experiment.py).
+// Layouts: lane (i, h) of an MFMA supplies K = 8 h .. 8 h + 7 of row / column i, so 16 input channels are one MFMA step and a
+// lane's operand is ONE 16-byte read of a pixel's channels: patches are [pixel][channel] bf16 (pitch + 16 bytes: conflict-
+// free ds_read_b128), one for the first pieces and one for the second; weights arrive pre-split from the host as
+// w[piece][tap][kb][h][cout][8]. Activations are split where they are written into LDS (staging, conv3's epilogue).
+constexpr int PA16 = C2 * 2 + 16;   // bytes per pixel of the conv3 input patches
+constexpr int PB16 = C3 * 2 + 16;   // ... of the conv4 input patches
+
+__device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+}
+
+__global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__ in, const bf16x8* __restrict__ w3s,
+                                                       const float* __restrict__ b3, const bf16x8* __restrict__ w4s,
+                                                       const float* __restrict__ b4, float* __restrict__ out, int Win,
+                                                       int xtiles, int64_t nwin) {
+    constexpr int NA = 6 * PW * PA16, NB = 4 * PW * PB16;     // bytes per piece
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    unsigned char* pAh = lds16;                               // [6][34] pixels x 32 channels: pooled conv2 rows -1..4
+    unsigned char* pAl = pAh + NA;
+    unsigned char* pBh = pAl + NA;                            // [4][34] pixels x 64 channels: conv3 rows 0..3
+    unsigned char* pBl = pBh + NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t win = blockIdx.x / xtiles;
+    const int xt = (int)(blockIdx.x - win * xtiles);
+    const int c0 = T34 * xt;
+    const int Wo4 = Win - 2, Wp = Wo4 / 2;
+    if (win >= nwin) return;
+
+    const float* img = in + win * (int64_t)4 * Win * C2;
+    for (int e = tid; e < 6 * PW * (C2 / 4); e += 256) {
+        const int r = e / (PW * (C2 / 4));
+        const int rem = e - r * (PW * (C2 / 4));
+        const int p = rem / (C2 / 4), c4 = rem - p * (C2 / 4);
+        const int yi = r - 1, xi = c0 - 1 + p;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yi >= 0 && yi < 4 && xi >= 0 && xi < Win)
+            v = *reinterpret_cast<const float4*>(img + ((int64_t)yi * Win + xi) * C2 + c4 * 4);
+        __bf16 h4[4], l4[4];
+        split_bf16(v.x, h4[0], l4[0]);
+        split_bf16(v.y, h4[1], l4[1]);
+        split_bf16(v.z, h4[2], l4[2]);
+        split_bf16(v.w, h4[3], l4[3]);
+        const bf16x4 vh = {h4[0], h4[1], h4[2], h4[3]}, vl = {l4[0], l4[1], l4[2], l4[3]};
+        *reinterpret_cast<bf16x4*>(pAh + (r * PW + p) * PA16 + c4 * 8) = vh;
+        *reinterpret_cast<bf16x4*>(pAl + (r * PW + p) * PA16 + c4 * 8) = vl;
+    }
+    for (int e = tid; e < 4 * 2 * (PB16 / 4); e += 256) {     // the two columns conv4's discarded outputs touch
+        const int r = e / (2 * (PB16 / 4)), rem = e - r * (2 * (PB16 / 4));
+        reinterpret_cast<unsigned*>(pBh + (r * PW + 32) * PB16)[rem] = 0u;
+        reinterpret_cast<unsigned*>(pBl + (r * PW + 32) * PB16)[rem] = 0u;
+    }
+    __syncthreads();
+
+    // ---- phase 1: conv3, row = wave, both N tiles ----
+    {
+        constexpr int KB = C2 / 16, NIT = 9 * KB;
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
+        const int pa0 = (wave * PW + i) * PA16 + h * 16;
+        const bf16x8* wh = w3s + h * C3 + i;                  // [tap][kb][h][cout]
+        const bf16x8* wl = wh + 9 * KB * 2 * C3;
+        // A (LDS) one step ahead; B (weights, L2: a step is only 192 matrix-core cycles) WD steps ahead
+        constexpr int WD = 4;
+        bf16x8 ah[2], al[2], bh[WD][2], bl[WD][2];
+        auto fetch_a = [&](int it, int buf) {
+            const int tap = it / KB, kb = it - tap * KB;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int off = pa0 + (dy * PW + dx) * PA16 + kb * 32;
+            ah[buf] = *reinterpret_cast<const bf16x8*>(pAh + off);
+            al[buf] = *reinterpret_cast<const bf16x8*>(pAl + off);
+        };
+        auto fetch_b = [&](int it, int slot) {
+            const int wo = it * 2 * C3;                       // (tap * KB + kb) = it
+            bh[slot][0] = wh[wo];
+            bh[slot][1] = wh[wo + 32];
+            bl[slot][0] = wl[wo];
+            bl[slot][1] = wl[wo + 32];
+        };
+#pragma unroll
+        for (int k = 0; k < WD - 1; ++k) fetch_b(k, k);
+        fetch_a(0, 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cur = it & 1, ws = it % WD;
+            if (it + WD - 1 < NIT) fetch_b(it + WD - 1, (it + WD - 1) % WD);
+            if (it + 1 < NIT) fetch_a(it + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[ws][nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[ws][nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[ws][nt], acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = nt * 32 + i;
+            const float bv = b3[co];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int px = (q & 3) + 8 * (q >> 2) + 4 * h;
+                __bf16 vh, vl;
+                split_bf16(fmaxf(acc[nt][q] + bv, 0.f), vh, vl);
+                *reinterpret_cast<__bf16*>(pBh + (wave * PW + px) * PB16 + co * 2) = vh;
+                *reinterpret_cast<__bf16*>(pBl + (wave * PW + px) * PB16 + co * 2) = vl;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: conv4, row = wave & 1, N tile = wave >> 1 ----
+    const int r4 = wave & 1, nt4 = wave >> 1;
+    f32x16 acc4;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc4[q] = 0.f;
+    {
+        constexpr int KB = C3 / 16, NIT = 9 * KB;
+        const int pa0 = (r4 * PW + i) * PB16 + h * 16;
+        const bf16x8* wh = w4s + h * C4 + nt4 * 32 + i;
+        const bf16x8* wl = wh + 9 * KB * 2 * C4;
+        constexpr int WD = 6;
+        bf16x8 ah[2], al[2], bh[WD], bl[WD];
+        auto fetch_a = [&](int it, int buf) {
+            const int tap = it / KB, kb = it - tap * KB;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int off = pa0 + (dy * PW + dx) * PB16 + kb * 32;
+            ah[buf] = *reinterpret_cast<const bf16x8*>(pBh + off);
+            al[buf] = *reinterpret_cast<const bf16x8*>(pBl + off);
+        };
+        auto fetch_b = [&](int it, int slot) {
+            bh[slot] = wh[it * 2 * C4];
+            bl[slot] = wl[it * 2 * C4];
+        };
+#pragma unroll
+        for (int k = 0; k < WD - 1; ++k) fetch_b(k, k);
+        fetch_a(0, 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cur = it & 1, ws = it % WD;
+            if (it + WD - 1 < NIT) fetch_b(it + WD - 1, (it + WD - 1) % WD);
+            if (it + 1 < NIT) fetch_a(it + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[ws], acc4, 0, 0, 0);
+            acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[ws], acc4, 0, 0, 0);
+            acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[ws], acc4, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // 2x2 pool as in k_conv34_mfma (the conv3 input patches are free)
+    float hm[8];
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) hm[q / 2] = fmaxf(acc4[q], acc4[q + 1]);
+    float* xch = reinterpret_cast<float*>(pAh) + nt4 * (8 * 64);
+    if (r4 == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xch[k * 64 + lane] = hm[k];
+    }
+    __syncthreads();
+    if (r4 == 0) {
+        const int co = nt4 * 32 + i;
+        const float bv = b4[co];
+        float* o = out + win * (int64_t)Wp * C4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = 2 * k;
+            const int xl = (q & 3) + 8 * (q >> 2) + 4 * h;
+            const int pxp = (c0 + xl) >> 1;
+            const float m = fmaxf(hm[k], xch[k * 64 + lane]);
+            if (xl < T34 && pxp < Wp) o[(int64_t)pxp * C4 + co] = fmaxf(m + bv, 0.f);
+        }
+    }
+}
+
+// ---- conv1 + conv2 + pool with conv2 on the bf16 matrix cores (as k_conv34_bf16x3; structure of k_conv12_mfma) ----
+// The conv2 input patch (computed by conv1, float32 VALU as before) is written as two bf16 pieces at 64 bytes per pixel:
+// no room for a padded pitch (four tasks per workgroup, two workgroups per CU), so the 16-byte chunk c of pixel p sits at
+// chunk c ^ ((p >> 2) & 3) - sixteen consecutive pixels then cover all sixteen bank quads for any chunk a wave reads.
+__device__ __forceinline__ int patch16_offset(int pixel, int chunk) { return pixel * 64 + ((chunk ^ ((pixel >> 2) & 3)) << 4); }
+
+#ifndef F2_C12_PAIRS
+#define F2_C12_PAIRS 2     // tasks (wave pairs) per workgroup: more, smaller workgroups interleave staging and matrix phases better (4: +6 %)
+#endif
+__global__ __launch_bounds__(128 * F2_C12_PAIRS) void k_conv12_bf16x3(const float* __restrict__ x, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const bf16x8* __restrict__ w2s,
+                                                       const float* __restrict__ b2, float* __restrict__ out, int Hin,
+                                                       int Win, int64_t nwin) {
+    constexpr int PIECE = 4 * PW * 64, XW = PW + 2, KB = C1 / 16, NIT = 9 * KB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = wave >> 1, r = wave & 1;
+    unsigned char* ph = lds16 + pair * (2 * PIECE);
+    unsigned char* pl = ph + PIECE;
+    float* xin = reinterpret_cast<float*>(lds16 + F2_C12_PAIRS * (2 * PIECE)) + pair * (6 * XW);
+
+    const int Ho = Hin - 2, Wo = Win - 2, Wout = Wo / 2;
+    const int row_pairs = Ho / 2, xtiles = ((Wo / 2) * 2 + 31) / 32;
+    const int64_t tasks = nwin * row_pairs * xtiles;
+    int64_t task = (int64_t)blockIdx.x * F2_C12_PAIRS + pair;
+    const bool live = task < tasks;
+    if (!live) task = tasks - 1;
+    const int xt = (int)(task % xtiles);
+    const int64_t t2 = task / xtiles;
+    const int rp = (int)(t2 % row_pairs);
+    const int64_t win = t2 / row_pairs;
+    const int y0 = 2 * rp, x0 = 32 * xt;
+
+    const float* img = x + win * (int64_t)Hin * Win;
+    const int l2 = lane + 64 * r;
+    for (int e = l2; e < 6 * XW; e += 128) {
+        const int r6 = e / XW, p6 = e - r6 * XW;
+        const int yi = y0 - 1 + r6, xi = x0 - 1 + p6;
+        xin[e] = (yi >= 0 && yi < Hin && xi >= 0 && xi < Win) ? img[(int64_t)yi * Win + xi] : 0.f;
+    }
+    const int c4 = l2 & 7, pg = l2 >> 3;
+    float wr[9][4], br[4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr[tap][q] = w1[tap * C1 + c4 * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) br[q] = b1[c4 * 4 + q];
+    __syncthreads();
+#pragma unroll 1
+    for (int e = pg; e < 4 * PW; e += 16) {
+        const int pr = e / PW, pc = e - pr * PW;
+        float xv[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) xv[dy * 3 + dx] = xin[(pr + dy) * XW + pc + dx];
+        __bf16 h4[4], l4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc = fmaf(xv[tap], wr[tap][q], acc);   // same order as the oracle's conv1
+            split_bf16(fmaxf(acc + br[q], 0.f), h4[q], l4[q]);
+        }
+        const int off = patch16_offset(e, c4 >> 1) + (c4 & 1) * 8;
+        *reinterpret_cast<bf16x4*>(ph + off) = bf16x4{h4[0], h4[1], h4[2], h4[3]};
+        *reinterpret_cast<bf16x4*>(pl + off) = bf16x4{l4[0], l4[1], l4[2], l4[3]};
+    }
+    __syncthreads();
+
+    const int i = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const int p0 = r * PW + i;
+    const bf16x8* wh = w2s + h * C2 + i;                      // [tap][kb][h][cout]
+    const bf16x8* wl = wh + 9 * KB * 2 * C2;
+    // A (LDS) one step ahead; B (weights, L2) WD steps ahead: a step is only 96 matrix-core cycles
+    constexpr int WD = 5;
+    bf16x8 ah[2], al[2], bh[WD], bl[WD];
+    auto fetch_a = [&](int it, int buf) {
+        const int tap = it / KB, kb = it - tap * KB;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int off = patch16_offset(p0 + dy * PW + dx, 2 * kb + h);
+        ah[buf] = *reinterpret_cast<const bf16x8*>(ph + off);
+        al[buf] = *reinterpret_cast<const bf16x8*>(pl + off);
+    };
+    auto fetch_b = [&](int it, int slot) {
+        bh[slot] = wh[it * 2 * C2];
+        bl[slot] = wl[it * 2 * C2];
+    };
+#pragma unroll
+    for (int k = 0; k < WD - 1; ++k) fetch_b(k, k);
+    fetch_a(0, 0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int cur = it & 1, ws = it % WD;
+        if (it + WD - 1 < NIT) fetch_b(it + WD - 1, (it + WD - 1) % WD);
+        if (it + 1 < NIT) fetch_a(it + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[ws], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[ws], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[ws], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float hm[8];
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) hm[q / 2] = fmaxf(acc[q], acc[q + 1]);
+    float* xch = reinterpret_cast<float*>(ph);
+    __syncthreads();
+    if (r == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xch[k * 64 + lane] = hm[k];
+    }
+    __syncthreads();
+    if (r == 0 && live) {
+        const float bv = b2[i];
+        float* o = out + win * (int64_t)row_pairs * Wout * C2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = 2 * k;
+            const int px = (x0 + (q & 3) + 8 * (q >> 2) + 4 * h) >> 1;
+            const float m = fmaxf(hm[k], xch[k * 64 + lane]);
+            if (px < Wout) o[((int64_t)rp * Wout + px) * C2 + i] = fmaxf(m + bv, 0.f);
+        }
+    }
+}
+
 // ---- dense1: (n, K) x (K, 516) on the same MFMA ----
 // One 6-wave workgroup = 64 windows (two M tiles) x 6 of the 17 output tiles (blockIdx.y picks the group, one output
 // tile per wave, every weight load feeds both M tiles). K is walked in
@@ -591,8 +906,18 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
             F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv12_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12));
             const int64_t blocks = (tasks + 3) / 4;
             F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
-            hipLaunchKernelGGL(k_conv12_mfma, dim3((unsigned)blocks), dim3(512), lds12, ctx->stream, d_x, cnn->t(0), cnn->t(1),
-                               cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n);
+            if (ctx->opt_cnn_bf16x3 && cnn->blob16) {
+                constexpr size_t lds12b = F2_C12_PAIRS * (2 * (size_t)(4 * PW * 64) + sizeof(float) * 6 * (PW + 2));
+                static_assert(lds12b <= 80 * 1024, "two workgroups per CU");
+                F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv12_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12b));
+                const int64_t blocks16 = (tasks + F2_C12_PAIRS - 1) / F2_C12_PAIRS;
+                F2_CHECK(ctx, blocks16 < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
+                hipLaunchKernelGGL(k_conv12_bf16x3, dim3((unsigned)blocks16), dim3(128 * F2_C12_PAIRS), lds12b, ctx->stream, d_x, cnn->t(0), cnn->t(1),
+                                   (const bf16x8*)(cnn->blob16 + cnn->off16[0]), cnn->t(3), a2, d.H1, d.W1, n);
+            } else {
+                hipLaunchKernelGGL(k_conv12_mfma, dim3((unsigned)blocks), dim3(512), lds12, ctx->stream, d_x, cnn->t(0), cnn->t(1),
+                                   cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n);
+            }
             F2_HIP(ctx, hipGetLastError());
         }
     }
@@ -604,8 +929,17 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
         F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv34_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds34));
         const int64_t blocks = n * xtiles;
         F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
-        hipLaunchKernelGGL(k_conv34_mfma, dim3((unsigned)blocks), dim3(256), lds34, ctx->stream, a2, cnn->t(4), cnn->t(5),
-                           cnn->t(6), cnn->t(7), a4, d.Wp1, xtiles, n);
+        if (ctx->opt_cnn_bf16x3 && cnn->blob16) {
+            constexpr size_t lds16 = 2 * (size_t)(6 * PW * PA16 + 4 * PW * PB16);
+            static_assert(lds16 <= 80 * 1024, "two workgroups per CU");
+            F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv34_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+            hipLaunchKernelGGL(k_conv34_bf16x3, dim3((unsigned)blocks), dim3(256), lds16, ctx->stream, a2,
+                               (const bf16x8*)(cnn->blob16 + cnn->off16[1]), cnn->t(5),
+                               (const bf16x8*)(cnn->blob16 + cnn->off16[2]), cnn->t(7), a4, d.Wp1, xtiles, n);
+        } else {
+            hipLaunchKernelGGL(k_conv34_mfma, dim3((unsigned)blocks), dim3(256), lds34, ctx->stream, a2, cnn->t(4), cnn->t(5),
+                               cnn->t(6), cnn->t(7), a4, d.Wp1, xtiles, n);
+        }
         F2_HIP(ctx, hipGetLastError());
     } else {
         F2_TRY((launch_conv<C2, C3, true, false, 8, 2>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
@@ -680,7 +1014,45 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
                     tensors[8][(size_t)k * D1 + nn];
         }
     }
-    for (int i = 0; i < 12; ++i) {
+    // conv2 .. conv4 kernels once more for the split-bf16 kernels: w[piece][tap][kb][h][cout][8] (channel = 16 kb + 8 h + e),
+    // piece 0 = bf16(w), piece 1 = bf16(w - piece 0), round to nearest even
+    std::vector<uint16_t> w16;
+    {
+        auto to_bf16 = [](float x) -> uint16_t {
+            uint32_t u;
+            memcpy(&u, &x, 4);
+            return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        };
+        auto from_bf16 = [](uint16_t b) -> float {
+            const uint32_t u = (uint32_t)b << 16;
+            float r;
+            memcpy(&r, &u, 4);
+            return r;
+        };
+        size_t pos = 0;
+        for (int l = 0; l < 3; ++l) {
+            const int ti = 2 + 2 * l, ci_n = conv_cin[l], co_n = conv_cout[l], kbn = ci_n / 16;
+            cnn->off16[l] = pos;
+            const size_t per_piece = (size_t)9 * ci_n * co_n;
+            w16.resize(pos + 2 * per_piece);
+            for (int tap = 0; tap < 9; ++tap)
+                for (int kb = 0; kb < kbn; ++kb)
+                    for (int hh = 0; hh < 2; ++hh)
+                        for (int co = 0; co < co_n; ++co)
+                            for (int e2 = 0; e2 < 8; ++e2) {
+                                const float wv = tensors[ti][((size_t)tap * ci_n + 16 * kb + 8 * hh + e2) * co_n + co];
+                                const uint16_t p0 = to_bf16(wv), p1 = to_bf16(wv - from_bf16(p0));
+                                const size_t idx = ((((size_t)tap * kbn + kb) * 2 + hh) * co_n + co) * 8 + e2;
+                                w16[pos + idx] = p0;
+                                w16[pos + per_piece + idx] = p1;
+                            }
+            pos += 2 * per_piece;
+        }
+    }
+    e = hipMalloc((void**)&cnn->blob16, w16.size() * sizeof(uint16_t));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(cnn->blob16, w16.data(), w16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream);
+    for (int i = 0; e == hipSuccess && i < 12; ++i) {
         const float* src = relaid[i].empty() ? tensors[i] : relaid[i].data();
         e = hipMemcpyAsync(cnn->blob + cnn->off[i], src, dev_sizes[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) break;
@@ -688,6 +1060,7 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         (void)hipFree(cnn->blob);
+        if (cnn->blob16) (void)hipFree(cnn->blob16);
         delete cnn;
         return f2_fail(ctx, F2_ERR_HIP, "uploading CNN weights -> %s", hipGetErrorString(e));
     }
@@ -699,6 +1072,7 @@ int f2_cnn_destroy(f2_ctx* ctx, f2_cnn* cnn) {
     if (!cnn) return F2_OK;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (cnn->blob) (void)hipFree(cnn->blob);
+    if (cnn->blob16) (void)hipFree(cnn->blob16);
     delete cnn;
     return F2_OK;
 }

@@ -85,6 +85,7 @@ struct f2_ctx {
     int opt_k1_queue = -1;                // unit queue of the filterbank for ragged batches (0 / 1)
     int opt_k1_qwaves = 0;                // waves of the queue launch (0 = from the batch)
     int opt_env_pair = 1;                 // on-chip kernel for rows of 32769..65536 samples
+    int opt_cnn_bf16x3 = 1;               // conv3 + conv4 on the bf16 matrix cores, operands split in two pieces (3 MFMAs per product)
     int opt_env_plan4 = 0;                // four-pass plan for every 1 s row (default: three passes where measured faster)
     f2_scratch flags;      // small device words (error flags)
     int* host_flags = nullptr;  // pinned mirror
@@ -96,6 +97,8 @@ struct f2_cnn {
     float* blob = nullptr;       // all tensors, device
     size_t off[12] = {0};        // element offsets of the 12 tensors in `blob`
     const float* t(int i) const { return blob + off[i]; }
+    uint16_t* blob16 = nullptr;  // conv2 .. conv4 kernels split into two bf16 pieces (f2_cnn.hip, k_conv12_bf16x3 / k_conv34_bf16x3)
+    size_t off16[3] = {0};       // element offsets of the three layers in `blob16`
 };
 
 // activation workspace (floats) the CNN needs per window
