@@ -5,9 +5,11 @@
 //                  -> Conv 3x3 same, 64 + ReLU -> Conv 3x3 valid, 64 + ReLU -> MaxPool 2x2
 //                  -> Flatten (H,W,C order) -> Dense 516 + ReLU -> Dense 2 -> softmax
 //
-// All arithmetic is float32 with float32 accumulation (what Keras/TensorFlow computes). conv2..conv4 and
-// dense1 (98 % of the 21.0 M MAC per window) run as implicit GEMMs on the f32-input matrix cores
-// (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain, so results are deterministic); weights are used in
+// Accumulation is float32 throughout (what Keras/TensorFlow computes). conv2..conv4 and dense1 (98 % of the 21.0 M MAC
+// per window) run as implicit GEMMs on the matrix cores: the f32-input ones (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf
+// chain, so results are deterministic) or, for conv2..conv4 by default (option cnn_bf16x3), the bf16 ones with both
+// operands split in two bf16 pieces - three MFMAs per product, scores within 1e-6 of the former (k_conv12_bf16x3,
+// k_conv34_bf16x3 below). In the float32 kernels the weights are used in
 // their Keras layouts: a (3,3,Cin,Cout) HWIO kernel flattened is exactly the K x N operand
 // (k = (dy*3+dx)*Cin + ci). Activations are NHWC in HBM between layers, processed in chunks of windows.
 //
@@ -466,10 +468,13 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
                                                        int xtiles, int64_t nwin) {
     constexpr int NA = 6 * PW * PA16, NB = 4 * PW * PB16;     // bytes per piece
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    // The second piece of the conv4 input lives where the conv3 input was (a barrier between conv3's matrix loop and its
+    // epilogue): 52 KB per workgroup instead of 72, three workgroups per CU instead of two.
+    static_assert(NB + 4096 <= 2 * NA, "conv4 input piece + pool exchange inside the conv3 input patches");
     unsigned char* pAh = lds16;                               // [6][34] pixels x 32 channels: pooled conv2 rows -1..4
     unsigned char* pAl = pAh + NA;
     unsigned char* pBh = pAl + NA;                            // [4][34] pixels x 64 channels: conv3 rows 0..3
-    unsigned char* pBl = pBh + NB;
+    unsigned char* pBl = lds16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int64_t win = blockIdx.x / xtiles;
@@ -495,11 +500,6 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
         const bf16x4 vh = {h4[0], h4[1], h4[2], h4[3]}, vl = {l4[0], l4[1], l4[2], l4[3]};
         *reinterpret_cast<bf16x4*>(pAh + (r * PW + p) * PA16 + c4 * 8) = vh;
         *reinterpret_cast<bf16x4*>(pAl + (r * PW + p) * PA16 + c4 * 8) = vl;
-    }
-    for (int e = tid; e < 4 * 2 * (PB16 / 4); e += 256) {     // the two columns conv4's discarded outputs touch
-        const int r = e / (2 * (PB16 / 4)), rem = e - r * (2 * (PB16 / 4));
-        reinterpret_cast<unsigned*>(pBh + (r * PW + 32) * PB16)[rem] = 0u;
-        reinterpret_cast<unsigned*>(pBl + (r * PW + 32) * PB16)[rem] = 0u;
     }
     __syncthreads();
 
@@ -547,6 +547,12 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[ws][nt], acc[nt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                      // every wave is done reading the conv3 input
+        for (int e = tid; e < 4 * 2 * (PB16 / 4); e += 256) { // the two columns conv4's discarded outputs touch
+            const int r = e / (2 * (PB16 / 4)), rem = e - r * (2 * (PB16 / 4));
+            reinterpret_cast<unsigned*>(pBh + (r * PW + 32) * PB16)[rem] = 0u;
+            reinterpret_cast<unsigned*>(pBl + (r * PW + 32) * PB16)[rem] = 0u;
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
     float hm[8];
 #pragma unroll
     for (int q = 0; q < 16; q += 2) hm[q / 2] = fmaxf(acc4[q], acc4[q + 1]);
-    float* xch = reinterpret_cast<float*>(pAh) + nt4 * (8 * 64);
+    float* xch = reinterpret_cast<float*>(lds16 + ((NB + 1023) & ~1023)) + nt4 * (8 * 64);   // behind the conv4 input piece
     if (r4 == 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) xch[k * 64 + lane] = hm[k];
@@ -930,8 +936,8 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
         const int64_t blocks = n * xtiles;
         F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
         if (ctx->opt_cnn_bf16x3 && cnn->blob16) {
-            constexpr size_t lds16 = 2 * (size_t)(6 * PW * PA16 + 4 * PW * PB16);
-            static_assert(lds16 <= 80 * 1024, "two workgroups per CU");
+            constexpr size_t lds16 = 2 * (size_t)(6 * PW * PA16) + (size_t)(4 * PW * PB16);
+            static_assert(3 * lds16 <= 160 * 1024, "three workgroups per CU");
             F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv34_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
             hipLaunchKernelGGL(k_conv34_bf16x3, dim3((unsigned)blocks), dim3(256), lds16, ctx->stream, a2,
                                (const bf16x8*)(cnn->blob16 + cnn->off16[1]), cnn->t(5),

@@ -78,6 +78,9 @@ const char* f2_last_error(f2_ctx* ctx);
  *   "k1_qwaves"      0 / n             waves of the queue launch (0 = from the batch)
  *   "env_pair"       1 / 0             on-chip envelope kernel for rows of 32769..65536 samples
  *   "env_plan4"      0 / 1             four-pass transform plan for every 8193..16384-sample row
+ *   "cnn_bf16x3"     1 (default) / 0   conv2..conv4 of f2_cnn_* / f2_eval_* on the bf16 matrix cores with both operands
+ *                                      split in two bf16 pieces (three MFMAs per product, float32 accumulation: scores within
+ *                                      1e-6 of the float32 matrix path, 2.2 x its speed); 0 = v_mfma_f32_32x32x2_f32 throughout
  * Read-only (f2_ctx_get_option): "spectral_flagged" = utterances of the last fused call that the spectral kernel's
  * accuracy guard handed back to the two-kernel route (waits for the stream).
  * Two contexts on two host threads choose independently. */

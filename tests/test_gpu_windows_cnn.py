@@ -84,6 +84,34 @@ def test_cnn_forward_vs_oracle(rows, channels, n):
     np.testing.assert_array_equal(m.predict(x[..., None]), scores)       # (n,R,C,1) accepted like Keras
 
 
+@pytest.mark.parametrize("rows,channels", [(11, 128), (13, 40)])
+def test_cnn_f32_and_split_bf16_matrix_paths(rows, channels):
+    """conv2-conv4 run on the bf16 matrix cores with both operands split in two bf16 pieces (three MFMAs per product,
+    float32 accumulation; option cnn_bf16x3, default) or on the float32 matrix cores (0): both within the tolerance of
+    the oracle (Training.py:93-114), the split path within 2e-6 of the float32 one, same labels wherever the oracle's
+    margin is above that."""
+    ctx = _lib.default_context()
+    m = F2CNNModel.glorot(7, rows, channels, zero_bias=False)
+    x = np.random.default_rng(8).random((700, rows, channels)).astype(np.float32)
+    x[:8] = 0.0
+    for i in range(1, 8):
+        x[i, (i * 5) % rows, (i * 37) % channels] = 1.0 + i          # impulses: every tap / padding edge
+    ref = orc.cnn_forward(x, oracle_weights(m))
+    assert ctx.get_option("cnn_bf16x3") == 1
+    got = {}
+    try:
+        for opt in (0, 1):
+            ctx.set_option("cnn_bf16x3", opt)
+            got[opt] = m.predict(x, ctx)
+            np.testing.assert_allclose(got[opt], ref, atol=2e-5)
+    finally:
+        ctx.set_option("cnn_bf16x3", 1)
+    assert np.abs(got[1] - got[0]).max() <= 2e-6
+    assert not np.array_equal(got[1], got[0])                         # (the option is not a no-op)
+    clear = np.abs(ref[:, 1] - ref[:, 0]) > 1e-5
+    np.testing.assert_array_equal((got[1][:, 1] > got[1][:, 0])[clear], (got[0][:, 1] > got[0][:, 0])[clear])
+
+
 def test_cnn_structured_inputs():
     # a shifted impulse probes every tap / padding edge of the conv stack; zeros probe the biases
     m = F2CNNModel.glorot(11, zero_bias=False)
