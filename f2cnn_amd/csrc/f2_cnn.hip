@@ -841,6 +841,114 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __re
     }
 }
 
+// ---- dense1 on the bf16 matrix cores, operands split in two pieces (as the convolutions above) ----
+// Same tiling as k_dense1_mfma (64 windows x 6 output tiles per 6-wave workgroup, K in chunks of 64). A chunk is only 24
+// MFMAs per wave now, so the next chunk's activations (global -> registers) and weights (8 x 16 bytes per lane) are
+// requested before the current chunk's MFMAs and land while they run; the activations are split when they are written to
+// LDS ([row][64] bf16 per piece, pitch + 16 bytes). Weights: w[piece][chunk][ks][h][n (544)][8], k = 64 chunk + 16 ks + 8 h + e.
+constexpr int D1_PITCH16 = D1_KC * 2 + 16;
+__global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_bf16x3(const float* __restrict__ a, const bf16x8* __restrict__ ws,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int K, int64_t n) {
+    constexpr int ROWS = 32 * D1_MT, NTHR = D1_WAVES * 64;
+    constexpr int PER = (ROWS * (D1_KC / 4) + NTHR - 1) / NTHR;      // float4 of a chunk per thread (3, the last partly)
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][ROWS * D1_PITCH16];
+    __shared__ __attribute__((aligned(16))) unsigned char Al[2][ROWS * D1_PITCH16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * ROWS;
+    const int i = lane & 31, h = lane >> 5;
+    const int nchunks = K / D1_KC;
+    const int nt = blockIdx.y * D1_WAVES + wave;
+    const bool live = nt < D1_TILES;
+    const int ntc = live ? nt : D1_TILES - 1;                        // (idle waves load a valid tile and discard it)
+    const bf16x8* wh = ws + (int64_t)h * D1_NPAD + ntc * 32 + i;
+    const bf16x8* wl = wh + (int64_t)nchunks * 4 * 2 * D1_NPAD;
+
+    float4 ar[PER];
+    auto load_a = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int e = tid + p * NTHR;
+            const int row = e / (D1_KC / 4), c4 = e - row * (D1_KC / 4);
+            const int64_t wr = w0 + row < n ? w0 + row : n - 1;
+            if (e < ROWS * (D1_KC / 4)) ar[p] = *reinterpret_cast<const float4*>(a + wr * K + (int64_t)kc * D1_KC + c4 * 4);
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int e = tid + p * NTHR;
+            const int row = e / (D1_KC / 4), c4 = e - row * (D1_KC / 4);
+            if (e < ROWS * (D1_KC / 4)) {
+                __bf16 h4[4], l4[4];
+                split_bf16(ar[p].x, h4[0], l4[0]);
+                split_bf16(ar[p].y, h4[1], l4[1]);
+                split_bf16(ar[p].z, h4[2], l4[2]);
+                split_bf16(ar[p].w, h4[3], l4[3]);
+                *reinterpret_cast<bf16x4*>(&Ah[buf][row * D1_PITCH16 + c4 * 8]) = bf16x4{h4[0], h4[1], h4[2], h4[3]};
+                *reinterpret_cast<bf16x4*>(&Al[buf][row * D1_PITCH16 + c4 * 8]) = bf16x4{l4[0], l4[1], l4[2], l4[3]};
+            }
+        }
+    };
+    bf16x8 bh[2][4], bl[2][4];
+    auto load_b = [&](int kc, int slot) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bh[slot][ks] = wh[(int64_t)(kc * 4 + ks) * 2 * D1_NPAD];
+            bl[slot][ks] = wl[(int64_t)(kc * 4 + ks) * 2 * D1_NPAD];
+        }
+    };
+
+    f32x16 acc[D1_MT];
+#pragma unroll
+    for (int t = 0; t < D1_MT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    load_a(0);
+    load_b(0, 0);
+    store_a(0);
+    __syncthreads();
+    auto chunk = [&](int kc, int cur) {                              // cur = kc & 1, compile-time in the unrolled pair below
+        if (kc + 1 < nchunks) {
+            load_a(kc + 1);
+            load_b(kc + 1, cur ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* pah = &Ah[cur][i * D1_PITCH16 + h * 16];
+        const unsigned char* pal = &Al[cur][i * D1_PITCH16 + h * 16];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int t = 0; t < D1_MT; ++t) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pah + t * 32 * D1_PITCH16 + ks * 32);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(pal + t * 32 * D1_PITCH16 + ks * 32);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cur][ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cur][ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cur][ks], acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 1 < nchunks) store_a(cur ^ 1);
+        __syncthreads();
+    };
+    for (int kc = 0; kc < nchunks; kc += 2) {
+        chunk(kc, 0);
+        if (kc + 1 < nchunks) chunk(kc + 1, 1);
+    }
+    const int col = nt * 32 + i;
+    if (live && col < D1) {
+        const float b = bias[col];
+#pragma unroll
+        for (int t = 0; t < D1_MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t wr = w0 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (wr < n) out[wr * D1 + col] = fmaxf(acc[t][q] + b, 0.f);
+            }
+    }
+}
+
 // ---- dense2 + softmax + label: one thread per window ----
 __global__ __launch_bounds__(256) void k_dense2_softmax(const float* __restrict__ a, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ scores,
@@ -952,8 +1060,12 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
         F2_TRY((launch_conv<C3, C4, false, true, 4, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
     }
     {
-        hipLaunchKernelGGL(k_dense1_mfma, dim3((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES), dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8),
-                           cnn->t(9), a5, d.flat, n);
+        const dim3 grid((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
+        if (ctx->opt_cnn_bf16x3 && cnn->blob16)
+            hipLaunchKernelGGL(k_dense1_bf16x3, grid, dim3(D1_WAVES * 64), 0, ctx->stream, a4,
+                               (const bf16x8*)(cnn->blob16 + cnn->off16[3]), cnn->t(9), a5, d.flat, n);
+        else
+            hipLaunchKernelGGL(k_dense1_mfma, grid, dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8), cnn->t(9), a5, d.flat, n);
         F2_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_dense2_softmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a5, cnn->t(10),
@@ -1052,6 +1164,22 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
                                 w16[pos + idx] = p0;
                                 w16[pos + per_piece + idx] = p1;
                             }
+            pos += 2 * per_piece;
+        }
+        {   // dense1: w[piece][chunk][ks][h][n (544, zero beyond 516)][8], k = 64 chunk + 16 ks + 8 h + e
+            cnn->off16[3] = pos;
+            const size_t per_piece = (size_t)d.flat * D1_NPAD;
+            w16.resize(pos + 2 * per_piece, 0);
+            for (int k = 0; k < d.flat; ++k) {
+                const int kc = k / D1_KC, kk = k % D1_KC, ks = kk / 16, hh = (kk % 16) / 8, e2 = kk % 8;
+                for (int nn = 0; nn < D1; ++nn) {
+                    const float wv = tensors[8][(size_t)k * D1 + nn];
+                    const uint16_t p0 = to_bf16(wv), p1 = to_bf16(wv - from_bf16(p0));
+                    const size_t idx = ((((size_t)kc * 4 + ks) * 2 + hh) * D1_NPAD + nn) * 8 + e2;
+                    w16[pos + idx] = p0;
+                    w16[pos + per_piece + idx] = p1;
+                }
+            }
             pos += 2 * per_piece;
         }
     }

@@ -97,8 +97,8 @@ struct f2_cnn {
     float* blob = nullptr;       // all tensors, device
     size_t off[12] = {0};        // element offsets of the 12 tensors in `blob`
     const float* t(int i) const { return blob + off[i]; }
-    uint16_t* blob16 = nullptr;  // conv2 .. conv4 kernels split into two bf16 pieces (f2_cnn.hip, k_conv12_bf16x3 / k_conv34_bf16x3)
-    size_t off16[3] = {0};       // element offsets of the three layers in `blob16`
+    uint16_t* blob16 = nullptr;  // conv2 .. conv4 and dense1 kernels split into two bf16 pieces (f2_cnn.hip, k_*_bf16x3)
+    size_t off16[4] = {0};       // element offsets of the four layers in `blob16`
 };
 
 // activation workspace (floats) the CNN needs per window
