@@ -639,41 +639,45 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
 // chunk c ^ ((p >> 2) & 3) - sixteen consecutive pixels then cover all sixteen bank quads for any chunk a wave reads.
 __device__ __forceinline__ int patch16_offset(int pixel, int chunk) { return pixel * 64 + ((chunk ^ ((pixel >> 2) & 3)) << 4); }
 
-#ifndef F2_C12_PAIRS
-#define F2_C12_PAIRS 2     // tasks (wave pairs) per workgroup: more, smaller workgroups interleave staging and matrix phases better (4: +6 %)
-#endif
-__global__ __launch_bounds__(128 * F2_C12_PAIRS) void k_conv12_bf16x3(const float* __restrict__ x, const float* __restrict__ w1,
-                                                       const float* __restrict__ b1, const bf16x8* __restrict__ w2s,
-                                                       const float* __restrict__ b2, float* __restrict__ out, int Hin,
-                                                       int Win, int64_t nwin) {
-    constexpr int PIECE = 4 * PW * 64, XW = PW + 2, KB = C1 / 16, NIT = 9 * KB;
+// RP = pooled rows (conv2 row pairs) per task, TPW = tasks per workgroup; a task is 2 RP waves, one per conv2 output row,
+// sharing a (2 RP + 2)-row patch: with RP = 2 conv1 computes six patch rows for four output rows instead of eight (its
+// float32 VALU work is what bounds the kernel: 968 VALU instructions per wave against 54 MFMAs at RP = 1), and the raw-input
+// loads, the conv1 weight loads and the barriers are shared by twice the output.
+template <int RP, int TPW>
+__global__ __launch_bounds__(128 * RP * TPW) void k_conv12_bf16x3(const float* __restrict__ x, const float* __restrict__ w1,
+                                                                   const float* __restrict__ b1, const bf16x8* __restrict__ w2s,
+                                                                   const float* __restrict__ b2, float* __restrict__ out, int Hin,
+                                                                   int Win, int64_t nwin) {
+    constexpr int PR = 2 * RP + 2, PIECE = PR * PW * 64, XW = PW + 2, XR = PR + 2, KB = C1 / 16, NIT = 9 * KB;
+    constexpr int TW = 2 * RP;                                 // waves per task
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pair = wave >> 1, r = wave & 1;
-    unsigned char* ph = lds16 + pair * (2 * PIECE);
+    const int tk = wave / TW, r = wave % TW;                   // r: the conv2 output row of the task this wave computes
+    unsigned char* ph = lds16 + tk * (2 * PIECE);
     unsigned char* pl = ph + PIECE;
-    float* xin = reinterpret_cast<float*>(lds16 + F2_C12_PAIRS * (2 * PIECE)) + pair * (6 * XW);
+    float* xin = reinterpret_cast<float*>(lds16 + TPW * (2 * PIECE)) + tk * (XR * XW);
 
     const int Ho = Hin - 2, Wo = Win - 2, Wout = Wo / 2;
-    const int row_pairs = Ho / 2, xtiles = ((Wo / 2) * 2 + 31) / 32;
-    const int64_t tasks = nwin * row_pairs * xtiles;
-    int64_t task = (int64_t)blockIdx.x * F2_C12_PAIRS + pair;
+    const int row_pairs = Ho / 2, row_groups = row_pairs / RP, xtiles = ((Wo / 2) * 2 + 31) / 32;   // (host: RP divides row_pairs)
+    const int64_t tasks = nwin * row_groups * xtiles;
+    int64_t task = (int64_t)blockIdx.x * TPW + tk;
     const bool live = task < tasks;
     if (!live) task = tasks - 1;
     const int xt = (int)(task % xtiles);
     const int64_t t2 = task / xtiles;
-    const int rp = (int)(t2 % row_pairs);
-    const int64_t win = t2 / row_pairs;
-    const int y0 = 2 * rp, x0 = 32 * xt;
+    const int rg = (int)(t2 % row_groups);
+    const int64_t win = t2 / row_groups;
+    const int y0 = 2 * RP * rg, x0 = 32 * xt;
 
+    // raw input region rows y0-1..y0+PR, cols x0-1..x0+34 (zero outside the window: conv1's 'same' padding)
     const float* img = x + win * (int64_t)Hin * Win;
-    const int l2 = lane + 64 * r;
-    for (int e = l2; e < 6 * XW; e += 128) {
+    const int l2 = lane + 64 * r;                              // 0 .. 64 TW - 1 inside the task
+    for (int e = l2; e < XR * XW; e += 64 * TW) {
         const int r6 = e / XW, p6 = e - r6 * XW;
         const int yi = y0 - 1 + r6, xi = x0 - 1 + p6;
         xin[e] = (yi >= 0 && yi < Hin && xi >= 0 && xi < Win) ? img[(int64_t)yi * Win + xi] : 0.f;
     }
-    const int c4 = l2 & 7, pg = l2 >> 3;
+    const int c4 = l2 & 7, pg = l2 >> 3;                       // 8 channel quads x 8 TW pixel groups
     float wr[9][4], br[4];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(128 * F2_C12_PAIRS) void k_conv12_bf16x3(const floa
     for (int q = 0; q < 4; ++q) br[q] = b1[c4 * 4 + q];
     __syncthreads();
 #pragma unroll 1
-    for (int e = pg; e < 4 * PW; e += 16) {
+    for (int e = pg; e < PR * PW; e += 8 * TW) {
         const int pr = e / PW, pc = e - pr * PW;
         float xv[9];
 #pragma unroll
@@ -739,18 +743,21 @@ __global__ __launch_bounds__(128 * F2_C12_PAIRS) void k_conv12_bf16x3(const floa
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[ws], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // 2x2 pool: horizontal pairs sit in one lane; the odd row of a pair hands its eight pair maxima to the even one through
+    // the (now idle) patch
     float hm[8];
 #pragma unroll
     for (int q = 0; q < 16; q += 2) hm[q / 2] = fmaxf(acc[q], acc[q + 1]);
-    float* xch = reinterpret_cast<float*>(ph);
+    float* xch = reinterpret_cast<float*>(ph) + (r >> 1) * (8 * 64);
     __syncthreads();
-    if (r == 1) {
+    if (r & 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) xch[k * 64 + lane] = hm[k];
     }
     __syncthreads();
-    if (r == 0 && live) {
+    if (!(r & 1) && live) {
         const float bv = b2[i];
+        const int rp = RP * rg + (r >> 1);
         float* o = out + win * (int64_t)row_pairs * Wout * C2;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -760,6 +767,22 @@ __global__ __launch_bounds__(128 * F2_C12_PAIRS) void k_conv12_bf16x3(const floa
             if (px < Wout) o[((int64_t)rp * Wout + px) * C2 + i] = fmaxf(m + bv, 0.f);
         }
     }
+}
+
+template <int RP, int TPW>
+int launch_conv12_bf16(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, float* a2, int H1, int W1, int64_t n) {
+    const int Ho = H1 - 2, Wo = W1 - 2;
+    const int64_t tasks = n * (Ho / 2 / RP) * (((Wo / 2) * 2 + 31) / 32);
+    if (tasks <= 0) return F2_OK;
+    constexpr size_t lds = TPW * (2 * (size_t)((2 * RP + 2) * PW * 64) + sizeof(float) * (2 * RP + 4) * (PW + 2));
+    static_assert(lds <= 80 * 1024, "at least two workgroups per CU");
+    auto kern = k_conv12_bf16x3<RP, TPW>;
+    F2_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t blocks = (tasks + TPW - 1) / TPW;
+    F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(128 * RP * TPW), lds, ctx->stream, d_x, cnn->t(0), cnn->t(1),
+                       (const bf16x8*)(cnn->blob16 + cnn->off16[0]), cnn->t(3), a2, H1, W1, n);
+    return F2_OK;
 }
 
 // ---- dense1: (n, K) x (K, 516) on the same MFMA ----
@@ -1021,13 +1044,9 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
             const int64_t blocks = (tasks + 3) / 4;
             F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
             if (ctx->opt_cnn_bf16x3 && cnn->blob16) {
-                constexpr size_t lds12b = F2_C12_PAIRS * (2 * (size_t)(4 * PW * 64) + sizeof(float) * 6 * (PW + 2));
-                static_assert(lds12b <= 80 * 1024, "two workgroups per CU");
-                F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv12_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12b));
-                const int64_t blocks16 = (tasks + F2_C12_PAIRS - 1) / F2_C12_PAIRS;
-                F2_CHECK(ctx, blocks16 < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
-                hipLaunchKernelGGL(k_conv12_bf16x3, dim3((unsigned)blocks16), dim3(128 * F2_C12_PAIRS), lds12b, ctx->stream, d_x, cnn->t(0), cnn->t(1),
-                                   (const bf16x8*)(cnn->blob16 + cnn->off16[0]), cnn->t(3), a2, d.H1, d.W1, n);
+                // four output rows per task where the pooled height allows (the reference's 11-row windows: 4 pooled rows)
+                if ((Ho / 2) % 2 == 0) F2_TRY((launch_conv12_bf16<2, 1>(ctx, cnn, d_x, a2, d.H1, d.W1, n)));
+                else F2_TRY((launch_conv12_bf16<1, 2>(ctx, cnn, d_x, a2, d.H1, d.W1, n)));
             } else {
                 hipLaunchKernelGGL(k_conv12_mfma, dim3((unsigned)blocks), dim3(512), lds12, ctx->stream, d_x, cnn->t(0), cnn->t(1),
                                    cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n);
