@@ -128,7 +128,7 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     f2_scratch* all[] = {&ctx->coefs, &ctx->offsets, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux,
-                         &ctx->work,  &ctx->work2,   &ctx->xbuf,      &ctx->flags};
+                         &ctx->work,  &ctx->work2,   &ctx->xbuf,      &ctx->flags,    &ctx->gather_log};
     for (f2_scratch* s : all)
         if (s->ptr) (void)hipFree(s->ptr);
     for (auto& v : ctx->prof)
@@ -212,6 +212,7 @@ const opt_entry kOptions[] = {
     {"env_pair", &f2_ctx::opt_env_pair, nullptr, 0, 1},
     {"env_plan4", &f2_ctx::opt_env_plan4, nullptr, 0, 1},
     {"cnn_bf16x3", &f2_ctx::opt_cnn_bf16x3, nullptr, 0, 1},
+    {"gather_blocked", &f2_ctx::opt_gather_blocked, nullptr, 0, 1},
 };
 const opt_entry* find_option(const char* key) {
     if (!key) return nullptr;

@@ -73,7 +73,129 @@ __global__ __launch_bounds__(GT) void k_gather_windows(const double* __restrict_
     for (int idx = tid; idx < total; idx += GT) o[idx] = (float)((log(win[idx]) - lmn) / range);
 }
 
+// ---- every-sample windows (`cnn eval`: centres first_center + e, normalised): two passes over coalesced data ----
+// A sample of the envelope matrix appears in 2 * radius + 1 windows per channel; the per-window kernel above reads it with
+// an 8-byte strided access and takes its logarithm (float64) each time. Here:
+//   k_log_columns:   L[c][t] = ln env[c][t] once per sample (coalesced in t), with the minimum / maximum over each group of 16
+//                    channels - a window's minimum is the minimum of R x groups of those;
+//   k_eval_windows:  a workgroup = WB consecutive windows x one tap k; it reads, per channel, the WB consecutive values
+//                    L[c][centre_0 + w + step (k - radius)] (one 256-byte run instead of 32 strided reads), normalises with
+//                    the window's (ln min, range) and turns the (window, channel) tile through LDS into 512-byte output rows.
+// Same arithmetic as k_gather_windows - ln v, ln min, (ln v - ln min) / range in float64, then float32 - so the results are
+// bit-identical to it (tests/test_gpu_windows_cnn.py compares the two).
+constexpr int WB = 32;      // consecutive windows per workgroup
+constexpr int LCH = 16;     // channels per thread of k_log_columns (its grid's second dimension walks the channel groups)
+
+__global__ __launch_bounds__(256) void k_log_columns(const double* __restrict__ env, int C, int64_t N, int64_t t0, int64_t span,
+                                                     double* __restrict__ L, double* __restrict__ pmin,
+                                                     double* __restrict__ pmax) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= span) return;
+    const int64_t t = t0 + j;
+    const int c0 = blockIdx.y * LCH, c1 = min(C, c0 + LCH);
+    double mn = INFINITY, mx = -INFINITY;
+    if (t >= 0 && t < N) {
+        for (int c = c0; c < c1; ++c) {
+            const double v = env[(size_t)c * (size_t)N + (size_t)t];
+            L[(size_t)c * (size_t)span + (size_t)j] = log(v);
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+    }
+    pmin[(size_t)blockIdx.y * (size_t)span + (size_t)j] = mn;     // minimum / maximum over this group's channels
+    pmax[(size_t)blockIdx.y * (size_t)span + (size_t)j] = mx;
+}
+
+// grid (blocks of WB windows, taps): every workgroup forms the statistics of its WB windows again (R x groups loads per window)
+__global__ __launch_bounds__(256) void k_eval_windows(const double* __restrict__ L, const double* __restrict__ pmin,
+                                                      const double* __restrict__ pmax, int C, int groups, int64_t span,
+                                                      int64_t n_windows, int radius, int step, float* __restrict__ out,
+                                                      int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* tile = reinterpret_cast<float*>(smem_raw);            // [WB][C + 1]
+    __shared__ double s_lmn[WB], s_range[WB];
+    __shared__ int s_zero[WB];
+    const int tid = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * WB;
+    const int k = blockIdx.y;
+    const int nw = (int)((n_windows - e0) < WB ? (n_windows - e0) : WB);
+    const int R = 2 * radius + 1, CP = C + 1;
+    // window e has its centre at span index e + step * radius (k_log_columns started `reach` samples before the first centre).
+    // Its R x groups partial minima are spread over the eight threads that share the window (a single thread walking all of
+    // them serialises ~90 L2 latencies in front of the workgroup's real work).
+    const int w = tid & (WB - 1), cc = tid / WB;                 // 8 channel lanes x 32 windows
+    __shared__ double s_pmn[256 / WB][WB], s_pmx[256 / WB][WB];
+    {
+        double mn = INFINITY, mx = -INFINITY;
+        if (w < nw) {
+            const int pairs = R * groups;
+#pragma unroll 4
+            for (int pq = cc; pq < pairs; pq += 256 / WB) {
+                const int k2 = pq / groups, g = pq - k2 * groups;
+                const size_t at = (size_t)g * (size_t)span + (size_t)(e0 + w + (int64_t)step * k2);
+                mn = fmin(mn, pmin[at]);
+                mx = fmax(mx, pmax[at]);
+            }
+        }
+        s_pmn[cc][w] = mn;
+        s_pmx[cc][w] = mx;
+    }
+    __syncthreads();
+    if (tid < WB) {
+        double mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 256 / WB; ++q) {
+            mn = fmin(mn, s_pmn[q][tid]);
+            mx = fmax(mx, s_pmx[q][tid]);
+        }
+        int zero = 0;
+        if (tid < nw && !(mn > 0.0)) {   // also catches NaN; the reference raises ValueError
+            if (k == 0) atomicOr(flag, 1);
+            zero = 1;
+        }
+        if (mn == mx) zero = 1;
+        const double lmn = log(mn);
+        s_lmn[tid] = lmn;
+        s_range[tid] = log(mx) - lmn;
+        s_zero[tid] = zero;
+    }
+    __syncthreads();
+    const double lmn = s_lmn[w], range = s_range[w];
+    const bool zero = s_zero[w] != 0, live = w < nw;
+    const double* Lk = L + (e0 + w + (int64_t)step * k);
+    for (int c = cc; c < C; c += 256 / WB) {
+        float o = 0.f;
+        if (live && !zero) o = (float)((Lk[(size_t)c * (size_t)span] - lmn) / range);
+        tile[w * CP + c] = o;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nw * C; idx += 256) {
+        const int ww = idx / C, c = idx - ww * C;
+        out[((size_t)(e0 + ww) * R + k) * (size_t)C + c] = tile[ww * CP + c];
+    }
+}
+
 }  // namespace
+
+static int launch_eval_windows(f2_ctx* ctx, const double* d_env, int C, int64_t N, int64_t first_center, int64_t n_windows,
+                               int radius, int step, float* d_out, int* d_flag) {
+    const int64_t reach = (int64_t)step * radius;
+    const int64_t span = n_windows + 2 * reach;
+    const int groups = (C + LCH - 1) / LCH;
+    F2_TRY(f2_reserve(ctx, ctx->gather_log, sizeof(double) * (size_t)span * ((size_t)C + 2 * (size_t)groups)));
+    double* L = (double*)ctx->gather_log.ptr;
+    double* pmin = L + (size_t)span * (size_t)C;
+    double* pmax = pmin + (size_t)span * (size_t)groups;
+    hipLaunchKernelGGL(k_log_columns, dim3((unsigned)((span + 255) / 256), (unsigned)groups), dim3(256), 0, ctx->stream, d_env, C, N,
+                       first_center - reach, span, L, pmin, pmax);
+    F2_HIP(ctx, hipGetLastError());
+    const size_t lds = sizeof(float) * WB * ((size_t)C + 1);
+    hipLaunchKernelGGL(k_eval_windows, dim3((unsigned)((n_windows + WB - 1) / WB), (unsigned)(2 * radius + 1)), dim3(256), lds,
+                       ctx->stream, (const double*)L, (const double*)pmin, (const double*)pmax, C, groups, span, n_windows, radius,
+                       step, d_out, d_flag);
+    F2_HIP(ctx, hipGetLastError());
+    return F2_OK;
+}
 
 int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const int64_t* d_centers,
                      int64_t first_center, int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag) {
@@ -85,6 +207,13 @@ int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const i
     if (lds > 64 * 1024)
         F2_HIP(ctx, hipFuncSetAttribute((const void*)k_gather_windows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     F2_TRY(f2_prof_begin(ctx, F2_K_GATHER));
+    // every-sample normalised windows (`cnn eval`): the two-pass coalesced form; anything else one workgroup per window
+    if (!d_centers && normalize && ctx->opt_gather_blocked && n_windows >= 4 * WB &&
+        sizeof(float) * WB * ((size_t)C + 1) <= 64 * 1024) {
+        F2_TRY(launch_eval_windows(ctx, d_env, C, N, first_center, n_windows, radius, step, d_out, d_flag));
+        F2_TRY(f2_prof_end(ctx, F2_K_GATHER));
+        return F2_OK;
+    }
     hipLaunchKernelGGL(k_gather_windows, dim3((unsigned)n_windows), dim3(GT), lds, ctx->stream, d_env, C, N, d_centers,
                        first_center, radius, step, normalize, d_out, d_flag);
     F2_HIP(ctx, hipGetLastError());

@@ -42,6 +42,7 @@ struct f2_ctx {
     f2_scratch work;       // intermediates (GFB between K1 and K2, activations, ...)
     f2_scratch work2;
     f2_scratch xbuf;       // window tensor chunk between K3 and K4
+    f2_scratch gather_log; // ln of the envelope samples a chunk of every-sample windows touches + column min / max (f2_gather.hip)
     f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
     f2_scratch tw_fl[16];         // twiddle tables of f2_envelope_flagged.hip, by log2 H
     f2_scratch tw_p3[2];   // the same for the three-pass plan of H = 8192 (f2_envelope_p3.hip), [precision]
@@ -86,6 +87,7 @@ struct f2_ctx {
     int opt_k1_qwaves = 0;                // waves of the queue launch (0 = from the batch)
     int opt_env_pair = 1;                 // on-chip kernel for rows of 32769..65536 samples
     int opt_cnn_bf16x3 = 1;               // conv3 + conv4 on the bf16 matrix cores, operands split in two pieces (3 MFMAs per product)
+    int opt_gather_blocked = 1;           // every-sample windows: logarithm once per sample, blocks of 32 windows (0: one workgroup per window)
     int opt_env_plan4 = 0;                // four-pass plan for every 1 s row (default: three passes where measured faster)
     f2_scratch flags;      // small device words (error flags)
     int* host_flags = nullptr;  // pinned mirror

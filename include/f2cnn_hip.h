@@ -81,6 +81,9 @@ const char* f2_last_error(f2_ctx* ctx);
  *   "cnn_bf16x3"     1 (default) / 0   conv2..conv4 of f2_cnn_* / f2_eval_* on the bf16 matrix cores with both operands
  *                                      split in two bf16 pieces (three MFMAs per product, float32 accumulation: scores within
  *                                      1e-6 of the float32 matrix path, 2.2 x its speed); 0 = v_mfma_f32_32x32x2_f32 throughout
+ *   "gather_blocked" 1 (default) / 0   every-sample normalised windows (f2_gather_windows without centres, f2_eval_*): logarithm
+ *                                      once per envelope sample and blocks of 32 consecutive windows, bit-identical to 0 = one
+ *                                      workgroup per window
  * Read-only (f2_ctx_get_option): "spectral_flagged" = utterances of the last fused call that the spectral kernel's
  * accuracy guard handed back to the two-kernel route (waits for the stream).
  * Two contexts on two host threads choose independently. */

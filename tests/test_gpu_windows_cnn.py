@@ -84,6 +84,35 @@ def test_cnn_forward_vs_oracle(rows, channels, n):
     np.testing.assert_array_equal(m.predict(x[..., None]), scores)       # (n,R,C,1) accepted like Keras
 
 
+@pytest.mark.parametrize("C,N", [(128, 16000), (40, 5000), (190, 4000), (3, 2100)])
+def test_every_sample_windows_blocked_and_per_window_kernels_agree(C, N):
+    """`cnn eval` windows (Evaluating.py:71-80 + Training.py:13-28): the two-pass form (logarithm once per sample, blocks of
+    32 consecutive windows; option gather_blocked, default) and the one-workgroup-per-window kernel give the same bits, and
+    a non-positive sample raises through either."""
+    ctx = _lib.default_context()
+    env = np.abs(np.random.default_rng(C).standard_normal((C, N))) + 1e-3
+    env[C // 2, N // 2:N // 2 + 400] = 0.25                     # a stretch of equal values
+    nb = N - 11 * 160
+    outs = {}
+    try:
+        for opt in (1, 0):
+            ctx.set_option("gather_blocked", opt)
+            out = np.empty((nb, 11, C), np.float32)
+            ctx.gather_windows(env, C, N, None, nb, 5, 160, True, out, _lib.MEM_HOST)
+            outs[opt] = out
+        np.testing.assert_array_equal(outs[1], outs[0])
+        np.testing.assert_allclose(outs[1][::97], orc.eval_input_tensor(env)[::97, ..., 0], atol=2e-7)
+        bad = env.copy()
+        bad[1, 900] = 0.0
+        for opt in (1, 0):
+            ctx.set_option("gather_blocked", opt)
+            with pytest.raises(_lib.F2Error) as e:
+                ctx.gather_windows(bad, C, N, None, nb, 5, 160, True, np.empty((nb, 11, C), np.float32), _lib.MEM_HOST)
+            assert e.value.code == _lib.F2_ERR_NONPOSITIVE      # -> ValueError("values must all be positive") in the drivers
+    finally:
+        ctx.set_option("gather_blocked", 1)
+
+
 @pytest.mark.parametrize("rows,channels", [(11, 128), (13, 40)])
 def test_cnn_f32_and_split_bf16_matrix_paths(rows, channels):
     """conv2-conv4 run on the bf16 matrix cores with both operands split in two bf16 pieces (three MFMAs per product,
