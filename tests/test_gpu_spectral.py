@@ -51,6 +51,22 @@ def test_ragged_batch_against_oracle_and_two_kernel_route(lpf):
         assert chan_relerr(g, o) <= 4e-6, len(w)
 
 
+def test_long_class_boundaries():
+    """Rows of 32769..65472 samples (four 16384-point transforms per row, magnitudes parked in the row's own output slot
+    as two banks of four planes, two low-pass sweeps): the lengths where a bank holds a handful of samples, where plane
+    sizes differ by one, where a low-pass block or the last transform block ends, and the longest the kernel serves."""
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 5, 100))
+    lens = [32769, 32770, 32771, 32772, 32773, 36863, 36864, 36865, 61439, 61440, 61441, 65469, 65470, 65471, 65472]
+    waves = [orc.synth_utterance(900 + i, n) for i, n in enumerate(lens)]
+    for lpf in (False, True):
+        got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
+        assert flagged == 0
+        for w, g in zip(waves, got):
+            assert not np.isnan(g).any()
+            assert chan_relerr(g, orc.filter_and_envelope(w, coefs, lpf, 50)) <= TOL, len(w)
+
+
 def test_float64_waves_and_small_tables():
     ctx = _lib.default_context()
     rng = np.random.default_rng(9)
