@@ -87,6 +87,62 @@ __device__ __forceinline__ void fft13_pass12_merged(cpx<float>* lds, const cpx<f
     __syncthreads();
 }
 
+// ---- the same for the 16-16-4-16 plan (H = 16384, 1024 threads, one radix-16 butterfly per thread in pass 1) ----
+// Pass 2 (radix 4, stride 256) combines the pass-1 outputs k of the four butterflies b = q + 16 (p' + 16 j'), j' = 0..3. With
+// butterfly (q, p') = (lane & 15, wave) and j' = lane >> 4, those sit in the lanes l, l + 16, l + 32, l + 48 of one wave: a 4 x 4
+// transpose over the lane quad - v_permlane32_swap on the register pairs (k, k + 8), then v_permlane16_swap on (k, k + 4)
+// and (k + 8, k + 12) - leaves in lane (hi, lo) = (j' >> 1, j' & 1) the four inputs (sources j' = 0..3 in the slots k, k + 4,
+// k + 8, k + 12) of the radix-4 butterflies of outputs kk = k + 4 lo + 8 hi, k < 4. 32 swaps replace 16 ds_write_b64 +
+// 16 ds_read_b64 and two barriers per transform. Measured bound (exchange skipped, results wrong): -15 % on
+// k_spectral_envelope<14>, -9 % on k_spectral_envelope_long.
+#define F2_SWAP8(OP, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7)                                        \
+    asm volatile("s_nop 1\n\t" OP " %0, %1\n\t" OP " %2, %3\n\t" OP " %4, %5\n\t" OP " %6, %7\n\t" OP " %8, %9\n\t" OP      \
+                 " %10, %11\n\t" OP " %12, %13\n\t" OP " %14, %15\n\ts_nop 1"                                                \
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3), "+v"(a4), "+v"(b4),       \
+                   "+v"(a5), "+v"(b5), "+v"(a6), "+v"(b6), "+v"(a7), "+v"(b7))
+template <int NT, int PTV>
+__device__ __forceinline__ void fft14_pass12_merged(cpx<float>* lds, const cpx<float>* twl, int tid, cpx<float> (&v)[PTV]) {
+    constexpr int LOG2H = 14;
+    static_assert(NT == 1024 && PTV >= 16 && plan_npass(LOG2H) == 4 && plan_bits(LOG2H, 0) == 4 && plan_bits(LOG2H, 1) == 4 &&
+                      plan_bits(LOG2H, 2) == 2 && plan_bits(LOG2H, 3) == 4, "the 16-16-4-16 plan on 1024 threads");
+    constexpr int OFF2 = plan_tw_offset(LOG2H, 2) - plan_tw_offset(LOG2H, 1);   // pass 2's table inside twl
+    const int l = tid & 63, wv = tid >> 6;
+    const int x = l & 15, jp = l >> 4;                  // q = x, p' = wv, pass-1 butterfly p = wv + 16 jp
+    const int b = x + 16 * (wv + 16 * jp);
+    const cpx<float>* src = lds + cpad(b);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = src[j * (1024 + 64)];   // cpad(b + 1024 j)
+    __syncthreads();
+    dft<16>(&v[0]);                                     // X[k] in v[brev<16>(k)]
+    const cpx<float>* t1 = twl + (wv + 16 * jp);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[brev<16>(k)] = cmul(v[brev<16>(k)], t1[(k - 1) * 64]);
+#define F2_S(k) v[brev<16>(k)]
+    // lanes (l, l + 32): slot k keeps / receives the values of output k + 8 hi from sources lo, slot k + 8 those of lo + 2
+    F2_SWAP8("v_permlane32_swap_b32", F2_S(0).re, F2_S(8).re, F2_S(0).im, F2_S(8).im, F2_S(1).re, F2_S(9).re, F2_S(1).im, F2_S(9).im,
+             F2_S(2).re, F2_S(10).re, F2_S(2).im, F2_S(10).im, F2_S(3).re, F2_S(11).re, F2_S(3).im, F2_S(11).im);
+    F2_SWAP8("v_permlane32_swap_b32", F2_S(4).re, F2_S(12).re, F2_S(4).im, F2_S(12).im, F2_S(5).re, F2_S(13).re, F2_S(5).im,
+             F2_S(13).im, F2_S(6).re, F2_S(14).re, F2_S(6).im, F2_S(14).im, F2_S(7).re, F2_S(15).re, F2_S(7).im, F2_S(15).im);
+    // lanes (l, l + 16): slot k + 4 s then holds source s of output k + 4 lo + 8 hi
+    F2_SWAP8("v_permlane16_swap_b32", F2_S(0).re, F2_S(4).re, F2_S(0).im, F2_S(4).im, F2_S(1).re, F2_S(5).re, F2_S(1).im, F2_S(5).im,
+             F2_S(2).re, F2_S(6).re, F2_S(2).im, F2_S(6).im, F2_S(3).re, F2_S(7).re, F2_S(3).im, F2_S(7).im);
+    F2_SWAP8("v_permlane16_swap_b32", F2_S(8).re, F2_S(12).re, F2_S(8).im, F2_S(12).im, F2_S(9).re, F2_S(13).re, F2_S(9).im,
+             F2_S(13).im, F2_S(10).re, F2_S(14).re, F2_S(10).im, F2_S(14).im, F2_S(11).re, F2_S(15).re, F2_S(11).im, F2_S(15).im);
+    const int kk0 = 4 * (jp & 1) + 8 * (jp >> 1);
+    const cpx<float>* t2 = twl + OFF2 + wv;             // p' = wv
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cpx<float> t[4] = {F2_S(k), F2_S(k + 4), F2_S(k + 8), F2_S(k + 12)};   // sources j' = 0..3
+        dft<4>(t);                                      // X[k2] in t[brev<4>(k2)]
+        const int pos = x + 16 * (k + kk0) + 1024 * wv; // q' + 1024 p', q' = q + 16 kk
+        lds[cpad(pos)] = t[0];
+#pragma unroll
+        for (int k2 = 1; k2 < 4; ++k2) lds[cpad(pos + 256 * k2)] = cmul(t[brev<4>(k2)], t2[(k2 - 1) * 16]);
+    }
+#undef F2_S
+    __syncthreads();
+}
+
 // First pass of TWO transforms of the same workgroup at once (radix-16 first pass, one butterfly per thread: 4096-,
 // 8192- and 16384-point rows) (the even-sample and the odd-sample transform
 // of k_spectral_envelope): thread t runs butterfly t of both, so the fifteen twiddles it derives from two loaded ones
@@ -142,6 +198,9 @@ __device__ __forceinline__ void fft_from_pass0(cpx<float>* lds, const cpx<float>
     if constexpr (LOG2H == 13) {
         fft13_pass12_merged<NT, PTV>(lds, twl, tid, v);
         fft_pass<float, 13, 3, false, true, PTV, NT, false, T0REGS>(lds, tw, twl, tid, v);
+    } else if constexpr (LOG2H == 14) {
+        fft14_pass12_merged<NT, PTV>(lds, twl, tid, v);
+        fft_pass<float, 14, 3, false, true, PTV, NT, false, T0REGS>(lds, tw, twl, tid, v);
     } else {
         fft_remaining_passes<LOG2H, PTV, NT, T0REGS>(lds, tw, twl, tid, v);
     }
