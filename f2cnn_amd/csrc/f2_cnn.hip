@@ -1035,7 +1035,11 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
     float* a4 = a3 + (size_t)n * d.Hp1 * d.Wp1 * C3;
     float* a5 = a4 + (size_t)n * d.flat;
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
-    {
+    const bool ws = ctx->opt_cnn_bf16x3 && ctx->opt_cnn_ws && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels);
+    if (ws) {
+        // weight-stationary persistent kernels (f2_cnn_ws.hip): conv1 on the matrix cores, one barrier per tile
+        F2_TRY(f2_launch_cnn_ws(ctx, cnn, d_x, n, a2, a4));
+    } else {
         // conv1 + conv2 + pool (conv1 is evaluated inside conv2's patch staging)
         const int Ho = d.H1 - 2, Wo = d.W1 - 2;
         const int64_t tasks = n * (Ho / 2) * (((Wo / 2) * 2 + 31) / 32);
@@ -1055,7 +1059,8 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
             F2_HIP(ctx, hipGetLastError());
         }
     }
-    if (d.Hp1 == 4) {
+    if (ws) {
+    } else if (d.Hp1 == 4) {
         // four pooled rows (the reference's 11-row windows): conv3 + conv4 + pool in one kernel, conv3's output stays in LDS
         const int xtiles = (2 * d.Wp2 + T34 - 1) / T34;
         constexpr size_t lds34 = sizeof(float) * (6 * PW * (C2 + 4) + 4 * PW * (C3 + 4));
@@ -1203,7 +1208,10 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
             pos += 2 * per_piece;
         }
     }
+    const size_t zeros_at = (w16.size() + 127) & ~size_t(127);
+    w16.resize(zeros_at + 128, 0);   // 256 zero bytes, 256-byte aligned
     e = hipMalloc((void**)&cnn->blob16, w16.size() * sizeof(uint16_t));
+    if (e == hipSuccess) cnn->zeros = cnn->blob16 + zeros_at;
     if (e == hipSuccess)
         e = hipMemcpyAsync(cnn->blob16, w16.data(), w16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream);
     for (int i = 0; e == hipSuccess && i < 12; ++i) {

@@ -537,7 +537,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         if (!split_groups[log2h].empty())
             F2_TRY(f2_launch_envelope_split(ctx, d_gfb, d_env, d_offsets, split_groups[log2h].data(),
                                             (int)split_groups[log2h].size(), log2h, C, P.lpf, P.b0, P.a1,
-                                            f32_in ? handoff->d_x32 : nullptr, f32_in ? handoff->d_x32_off : nullptr));
+                                            f32_in ? handoff->d_x32 : nullptr, f32_in ? handoff->d_x32_off : nullptr, d_uflag));
     size_t list_elems = 0;
     int ngroups = 0;
     for (auto& g : groups)

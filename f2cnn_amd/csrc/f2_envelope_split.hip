@@ -42,6 +42,7 @@ struct SplitParams {
     double* env;
     const int64_t* offsets;
     const int* ulist;          // utterances of this launch (device)
+    const int* uflag;          // per utterance of the batch, or NULL: rows of utterances whose flag is 0 are left alone
     int C;
     int lpf;
     double b0, a1;
@@ -60,6 +61,10 @@ struct Row {
     double* y;
     int n;
 };
+// utterances the spectral kernel has served (flag 0) are skipped by every pass: workgroup-uniform
+__device__ __forceinline__ bool row_skipped(const SplitParams& P, int r) {
+    return P.uflag && P.uflag[P.ulist[r / P.C]] == 0;
+}
 __device__ __forceinline__ Row row_of(const SplitParams& P, int r) {
     const int u = r / P.C, c = r - u * P.C;
     const int b = P.ulist[u];
@@ -80,6 +85,7 @@ __device__ __forceinline__ cpx<float> load_pair(const Row& rw, int i0) {
 template <int H1>
 __global__ __launch_bounds__(256) void k_split_first(SplitParams P) {
     const int r = blockIdx.x, n2 = blockIdx.y * 256 + threadIdx.x;
+    if (row_skipped(P, r)) return;
     const Row rw = row_of(P, r);
     cpx<float> v[H1];
 #pragma unroll
@@ -109,6 +115,7 @@ __global__ __launch_bounds__(2 * NTH, 4) void k_split_mid(SplitParams P) {
 
     const int tid = threadIdx.x, half = tid >> 8, t = tid & (NTH - 1);
     const int r = blockIdx.x, p = blockIdx.y;                // pair p = (p, H1 - p), 0 <= p <= H1/2
+    if (row_skipped(P, r)) return;
     const bool self = p == 0 || 2 * p == H1;                 // the sub-transform pairs with itself
     const int ka = half == 0 ? p : (H1 - p) % H1;
     cpx<float>* own = smem + half * CS;
@@ -160,6 +167,7 @@ __global__ __launch_bounds__(2 * NTH, 4) void k_split_mid(SplitParams P) {
 template <int H1>
 __global__ __launch_bounds__(256) void k_split_last(SplitParams P) {
     const int r = blockIdx.x, m2 = blockIdx.y * 256 + threadIdx.x;
+    if (row_skipped(P, r)) return;
     const Row rw = row_of(P, r);
     const cpx<float>* Cm = P.scratch + (size_t)r * (H1 * H2);
     cpx<float>* Ce = P.scratch + (size_t)r * (H1 * H2);
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(LNT, 2) void k_split_lowpass(SplitParams P) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[lowpass_lds_bytes<float, LNT, LNB>()];
     __shared__ float e_last;
     const int tid = threadIdx.x;
+    if (row_skipped(P, blockIdx.x)) return;
     const Row rw = row_of(P, blockIdx.x);
     double* y = rw.y;
     const int n = rw.n;
@@ -269,7 +278,7 @@ bool f2_envelope_split_supports(int log2h, int precision) {
 // All utterances `utts` (indices into the batch) have the same transform size 2^log2h complex points.
 int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets, const int* utts,
                              int nutt, int log2h, int C, int lpf, double b0, double a1, const float* d_x32,
-                             const int64_t* d_x32_off) {
+                             const int64_t* d_x32_off, const int* d_uflag) {
     if (nutt <= 0) return F2_OK;
     F2_CHECK(ctx, f2_envelope_split_supports(log2h, F2_FFT_F32), F2_ERR_INVALID, "unsupported split size 2^%d", log2h);
     const int H1 = 1 << (log2h - LOG2H2);
@@ -297,6 +306,7 @@ int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, co
     P.tw12 = (const cpx<float>*)ctx->tw[0][LOG2H2].ptr;
     P.x32 = d_x32;
     P.x32_off = d_x32_off;
+    P.uflag = d_uflag;
     for (int done = 0; done < nutt; done += per_group) {
         const int g = std::min(per_group, nutt - done);
         P.ulist = (const int*)ctx->work3.ptr + done;

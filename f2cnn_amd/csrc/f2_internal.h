@@ -87,6 +87,7 @@ struct f2_ctx {
     int opt_k1_qwaves = 0;                // waves of the queue launch (0 = from the batch)
     int opt_env_pair = 1;                 // on-chip kernel for rows of 32769..65536 samples
     int opt_cnn_bf16x3 = 1;               // conv3 + conv4 on the bf16 matrix cores, operands split in two pieces (3 MFMAs per product)
+    int opt_cnn_ws = 1;                   // ... with the weights of each wave's role held in registers (f2_cnn_ws.hip; windows of 10 / 11 rows)
     int opt_gather_blocked = 1;           // every-sample windows: logarithm once per sample, blocks of 32 windows (0: one workgroup per window)
     int opt_env_plan4 = 0;                // four-pass plan for every 1 s row (default: three passes where measured faster)
     f2_scratch flags;      // small device words (error flags)
@@ -101,6 +102,7 @@ struct f2_cnn {
     const float* t(int i) const { return blob + off[i]; }
     uint16_t* blob16 = nullptr;  // conv2 .. conv4 and dense1 kernels split into two bf16 pieces (f2_cnn.hip, k_*_bf16x3)
     size_t off16[4] = {0};       // element offsets of the four layers in `blob16`
+    const void* zeros = nullptr; // 256 zero bytes behind them (source of the padding pixels of f2_cnn_ws.hip's LDS-DMA loads)
 };
 
 // activation workspace (floats) the CNN needs per window
@@ -163,7 +165,7 @@ int f2_launch_envelope_flagged(f2_ctx* ctx, const f2_env_params& P, int log2h, u
 bool f2_envelope_split_supports(int log2h, int precision);
 int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets, const int* utts,
                              int nutt, int log2h, int C, int lpf, double b0, double a1, const float* d_x32,
-                             const int64_t* d_x32_off);
+                             const int64_t* d_x32_off, const int* d_uflag = nullptr);
 // rows of 32769..65536 samples, float transforms, input not aliased with the output: two LDS-resident sub-rows per workgroup
 bool f2_envelope_pair_supports(int log2h, int precision);
 int f2_launch_envelope_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* d_offsets,
@@ -209,6 +211,9 @@ int f2_launch_spectral(f2_ctx* ctx, const void* d_wave, int wave_dtype, const in
 // d_centers == NULL: window e is centred at first_center + e
 int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const int64_t* d_centers,
                      int64_t first_center, int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag);
+// weight-stationary split-bf16 convolutions (f2_cnn_ws.hip): windows whose pooled conv2 output has four rows
+bool f2_cnn_ws_supported(int rows, int channels);
+int f2_launch_cnn_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, void* a2s, float* a4);
 // runs the network on n windows (n <= chunk the workspace was sized for); d_ws: n * workspace floats
 int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_ws, float* d_scores,
                   uint8_t* d_labels);

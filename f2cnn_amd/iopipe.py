@@ -48,32 +48,44 @@ class JobReport:
         (an .npy whose header promises more bytes than the file holds - what a killed run leaves behind if it did not
         write through save_npy_atomic - counts as missing).
 
-        params / stamp_dir: the settings the outputs depend on (low-pass on / cutoff, ...) are written to
-        `<stamp_dir>/.f2cnn_<command>.rank<r>.json` when the run starts; a resume whose settings differ from the
-        stamp it finds recomputes everything instead of keeping outputs made with the other settings."""
-        stamp = None
+        params / stamp_dir: the settings the outputs depend on (low-pass on / cutoff, ...) live in ONE stamp per command,
+        `<stamp_dir>/.f2cnn_<command>.json` = {"params": ..., "since": time}. The stamp is rewritten only when the settings
+        change, with `since` = now, and from then on an output older than `since` is stale whatever run left it: a run
+        with new settings that dies part-way, resumed, recomputes exactly the outputs the old settings made. (Outputs
+        found without any stamp are trusted, `since` = 0. Every rank reads / writes the same file: a resume with another
+        world size sees the same stamp.)"""
+        since = 0.0
         if params is not None and stamp_dir is not None:
-            stamp = os.path.join(stamp_dir, ".f2cnn_{}.rank{}.json".format(self.command.replace(" ", "_"), self.rank))
+            stamp = os.path.join(stamp_dir, ".f2cnn_{}.json".format(self.command.replace(" ", "_")))
             previous = None
             try:
                 with open(stamp) as f:
                     previous = _json.load(f)
+                if not (isinstance(previous, dict) and "params" in previous and "since" in previous):
+                    previous = None
             except (OSError, ValueError):
                 pass
-            try:
-                with open(stamp, "w") as f:
-                    _json.dump(params, f)
-            except OSError:
-                pass
-            if self.skip_existing and previous is not None and previous != params:
-                print("Settings changed since the outputs were written ({} -> {}): nothing is skipped.".format(previous, params))
-                return list(items)
+            if previous is not None and previous["params"] == params:
+                since = float(previous["since"])
+            else:
+                since = _time.time() if previous is not None else 0.0
+                try:
+                    tmp = "{}.{}.tmp".format(stamp, os.getpid())
+                    with open(tmp, "w") as f:
+                        _json.dump({"params": params, "since": since}, f)
+                    os.replace(tmp, stamp)
+                except OSError:
+                    pass
+                if self.skip_existing and previous is not None:
+                    print("Settings changed since the outputs were written ({} -> {}): nothing is skipped.".format(
+                        previous["params"], params))
         if not self.skip_existing:
             return list(items)
         todo = []
         for it in items:
             outs = outputs_of(it)
-            fresh = all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(it) and npy_complete(o) for o in outs)
+            fresh = all(os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(it), since) and npy_complete(o)
+                        for o in outs)
             if fresh:
                 self.skipped += 1
             else:

@@ -99,14 +99,17 @@ def GenerateInputData(labelFile=None, inputFile=None, LPF=False, CUTOFF=100):
 
 
 def _run_token():
-    """What tells this launch's marker files from those a dead earlier launch left behind: the launcher's run id
-    ($F2CNN_RUN_ID, torchrun's $TORCHELASTIC_RUN_ID, else $MASTER_PORT). Ranks started by hand without any of them
-    share the token "0": export F2CNN_RUN_ID then."""
-    for key in ("F2CNN_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
-        v = os.environ.get(key)
-        if v:
-            return "".join(ch if ch.isalnum() else "_" for ch in v)
-    return "0"
+    """What tells this launch's marker files from those a dead earlier launch left behind. $F2CNN_RUN_ID when the launcher
+    exports one (ranks started by hand, in separate shells, must: they share nothing else). Otherwise torchrun's
+    $TORCHELASTIC_RUN_ID (the literal 'none' unless --rdzv-id is given) or $MASTER_PORT - the same on every launch - TOGETHER
+    WITH THE PARENT'S PID: the ranks of one single-node launch are children of one launcher process, and a relaunch after a
+    crash has another (round-3 advisor finding: a rank that met the dead launch's `ready` marker mapped the old file, which
+    rank 0 then replaced)."""
+    v = os.environ.get("F2CNN_RUN_ID")
+    if v:
+        return "".join(ch if ch.isalnum() else "_" for ch in v)
+    base = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT") or "0"
+    return "".join(ch if ch.isalnum() else "_" for ch in base) + "_p{}".format(os.getppid())
 
 
 def _marker(target, what, rank):

@@ -137,3 +137,27 @@ def test_small_batches_keep_the_two_kernel_route():
     ctx.prof_enable(False)
     assert "k_spectral_envelope" not in small and "k_spectral_envelope" in forced
     assert chan_relerr(a[0], b[0]) <= 4e-6 and chan_relerr(a[0], orc.filter_and_envelope(w[0], coefs, True, 50)) <= TOL
+
+
+@pytest.mark.parametrize("case", ["env_pair_off", "with_a_very_long_row"])
+def test_long_rows_served_by_the_spectral_kernel_are_not_recomputed_by_the_four_step_path(case):
+    """Rows of 32769..65472 samples whose fallback is the four-step envelope path - option env_pair = 0, or a batch that
+    also holds a row beyond 262144 samples (the call then hands float64 rows over in place) - used to be recomputed by
+    that path from a hand-off the filterbank kernel had skipped (round-3 advisor finding): every pass of the four-step
+    path now honours the per-utterance flags. A late click in the same batch still takes the fallback."""
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 8, 100))
+    click = np.zeros(40000, np.int16)
+    click[39995] = 32767
+    waves = [orc.synth_utterance(70, 40000), click, orc.synth_utterance(71, 40001), orc.synth_utterance(72, 9000)]
+    opts = {"spectral": 1}
+    if case == "env_pair_off":
+        opts["env_pair"] = 0
+    else:
+        waves.append(orc.synth_utterance(73, 300000))
+    for lpf in (False, True):
+        got, flagged = fused(ctx, waves, coefs, lpf, **opts)
+        assert flagged == 1
+        for w, g in zip(waves, got):
+            assert not np.isnan(g).any()
+            assert chan_relerr(g, orc.filter_and_envelope(w, coefs, lpf, 50)) <= TOL, (case, lpf, len(w))

@@ -113,12 +113,13 @@ def test_every_sample_windows_blocked_and_per_window_kernels_agree(C, N):
         ctx.set_option("gather_blocked", 1)
 
 
-@pytest.mark.parametrize("rows,channels", [(11, 128), (13, 40)])
+@pytest.mark.parametrize("rows,channels", [(11, 128), (13, 40), (10, 100), (11, 67)])
 def test_cnn_f32_and_split_bf16_matrix_paths(rows, channels):
     """conv2-conv4 run on the bf16 matrix cores with both operands split in two bf16 pieces (three MFMAs per product,
-    float32 accumulation; option cnn_bf16x3, default) or on the float32 matrix cores (0): both within the tolerance of
-    the oracle (Training.py:93-114), the split path within 2e-6 of the float32 one, same labels wherever the oracle's
-    margin is above that."""
+    float32 accumulation; option cnn_bf16x3, default) or on the float32 matrix cores (0); windows of 10 / 11 rows take the
+    weight-stationary kernels by default (option cnn_ws: conv1 on the matrix cores too, f2_cnn_ws.hip). All three within the
+    tolerance of the oracle (Training.py:93-114), the split paths within 2e-6 of the float32 one, same labels wherever the
+    oracle's margin is above that."""
     ctx = _lib.default_context()
     m = F2CNNModel.glorot(7, rows, channels, zero_bias=False)
     x = np.random.default_rng(8).random((700, rows, channels)).astype(np.float32)
@@ -126,19 +127,24 @@ def test_cnn_f32_and_split_bf16_matrix_paths(rows, channels):
     for i in range(1, 8):
         x[i, (i * 5) % rows, (i * 37) % channels] = 1.0 + i          # impulses: every tap / padding edge
     ref = orc.cnn_forward(x, oracle_weights(m))
-    assert ctx.get_option("cnn_bf16x3") == 1
+    assert ctx.get_option("cnn_bf16x3") == 1 and ctx.get_option("cnn_ws") == 1
     got = {}
     try:
-        for opt in (0, 1):
-            ctx.set_option("cnn_bf16x3", opt)
-            got[opt] = m.predict(x, ctx)
-            np.testing.assert_allclose(got[opt], ref, atol=2e-5)
+        for name, bf, ws in (("f32", 0, 0), ("bf16x3", 1, 0), ("ws", 1, 1)):
+            ctx.set_option("cnn_bf16x3", bf)
+            ctx.set_option("cnn_ws", ws)
+            got[name] = m.predict(x, ctx)
+            np.testing.assert_allclose(got[name], ref, atol=2e-5, err_msg=name)
     finally:
         ctx.set_option("cnn_bf16x3", 1)
-    assert np.abs(got[1] - got[0]).max() <= 2e-6
-    assert not np.array_equal(got[1], got[0])                         # (the option is not a no-op)
+        ctx.set_option("cnn_ws", 1)
     clear = np.abs(ref[:, 1] - ref[:, 0]) > 1e-5
-    np.testing.assert_array_equal((got[1][:, 1] > got[1][:, 0])[clear], (got[0][:, 1] > got[0][:, 0])[clear])
+    for name in ("bf16x3", "ws"):
+        assert np.abs(got[name] - got["f32"]).max() <= 2e-6, name
+        assert not np.array_equal(got[name], got["f32"]), name        # (the option is not a no-op)
+        np.testing.assert_array_equal((got[name][:, 1] > got[name][:, 0])[clear], (got["f32"][:, 1] > got["f32"][:, 0])[clear])
+    if rows in (10, 11):
+        assert not np.array_equal(got["ws"], got["bf16x3"])           # the weight-stationary kernels ran (conv1 differs)
 
 
 def test_cnn_structured_inputs():

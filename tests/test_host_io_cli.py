@@ -366,3 +366,13 @@ def test_atomic_npy_save_and_resume_check(tmp_path):
     assert rep.pending([str(src)], outs, params={"cutoff": 50}, stamp_dir=str(tmp_path)) == []
     rep2 = iopipe.JobReport("prepare envelope", skip_existing=True)
     assert rep2.pending([str(src)], outs, params={"cutoff": 100}, stamp_dir=str(tmp_path)) == [str(src)]
+    # that run dies before it rewrites the output: a resume with the SAME new settings must not trust the old output
+    # (round-3 advisor finding: the stamp used to be overwritten at the start, so the resume skipped everything)
+    rep3 = iopipe.JobReport("prepare envelope", skip_existing=True)
+    assert rep3.pending([str(src)], outs, params={"cutoff": 100}, stamp_dir=str(tmp_path)) == [str(src)]
+    import time
+    time.sleep(0.02)
+    iopipe.save_npy_atomic(str(tmp_path / "in.ENV1"), a)              # ... now it is recomputed
+    rep4 = iopipe.JobReport("prepare envelope", skip_existing=True)
+    assert rep4.pending([str(src)], outs, params={"cutoff": 100}, stamp_dir=str(tmp_path)) == [] and rep4.skipped == 1
+    assert sorted(f.name for f in tmp_path.iterdir() if f.name.startswith(".f2cnn")) == [".f2cnn_prepare_envelope.json"]

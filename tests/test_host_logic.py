@@ -84,3 +84,15 @@ def test_shared_output_markers_carry_the_launch_token(tmp_path, monkeypatch):
     assert np.load(target).shape == (3, 11, 4) and np.load(target)[1].min() == 1.0
     with pytest.raises(TimeoutError):          # a marker with another shape is not this launch's announcement either
         ig._shared_output(target, (4, 11, 4), 1, 2, timeout=0.3)
+    # torchrun without --rdzv-id exports the same run id ('none') and port for every launch: the launcher's pid separates them
+    monkeypatch.delenv("F2CNN_RUN_ID")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    monkeypatch.setattr(os, "getppid", lambda: 4242)
+    crashed = ig._run_token()
+    dead = ig._shared_output(target, (3, 11, 4), 0, 2)      # a launch that dies with its `ready` marker in place
+    del dead
+    monkeypatch.setattr(os, "getppid", lambda: 4343)
+    assert ig._run_token() != crashed and crashed.endswith("_p4242")
+    with pytest.raises(TimeoutError):          # same shape text, same run id, same port - but not this launch's marker
+        ig._shared_output(target, (3, 11, 4), 1, 2, timeout=0.3)
