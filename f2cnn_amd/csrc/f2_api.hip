@@ -239,18 +239,36 @@ int f2_ctx_set_option(f2_ctx* ctx, const char* key, double value) {
 
 int f2_ctx_get_option(f2_ctx* ctx, const char* key, double* value) {
     F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
-    if (key && value && strcmp(key, "spectral_flagged") == 0) {
-        // read-only: utterances of the last fused call that the spectral kernel's accuracy guard sent back to the
-        // filterbank kernel + envelope kernel (waits for the stream)
+    if (key && value && strncmp(key, "spectral_routed", 15) == 0) {
+        // read-only: utterances (or, "..._samples", their samples) the last fused call sent through the spectral kernel
+        const bool samples = strcmp(key, "spectral_routed_samples") == 0;
+        F2_CHECK(ctx, samples || strcmp(key, "spectral_routed") == 0, F2_ERR_INVALID, "unknown option '%s'", key);
+        *value = 0;
+        const size_t B = ctx->spec_last_B;
+        if (B == 0 || ctx->spec_meta_host.size() < B || ctx->offsets_host.size() != B + 1) return F2_OK;
+        double acc = 0;
+        for (size_t b = 0; b < B; ++b)
+            if (ctx->spec_meta_host[b] == 0) acc += samples ? (double)(ctx->offsets_host[b + 1] - ctx->offsets_host[b]) : 1.0;
+        *value = acc;
+        return F2_OK;
+    }
+    if (key && value && strncmp(key, "spectral_flagged", 16) == 0) {
+        // read-only: utterances ("..._samples": their samples) of the last fused call that the spectral kernel's accuracy
+        // guard sent back to the filterbank kernel + envelope kernel (waits for the stream)
+        const bool samples = strcmp(key, "spectral_flagged_samples") == 0;
+        F2_CHECK(ctx, samples || strcmp(key, "spectral_flagged") == 0, F2_ERR_INVALID, "unknown option '%s'", key);
         *value = 0;
         const size_t B = ctx->spec_last_B;
         if (B == 0 || !ctx->spec_uflag.ptr || ctx->spec_meta_host.size() < B) return F2_OK;
         std::vector<int> flags(B);
         F2_HIP(ctx, hipMemcpyAsync(flags.data(), ctx->spec_uflag.ptr, sizeof(int) * B, hipMemcpyDeviceToHost, ctx->stream));
         F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        int cnt = 0;
-        for (size_t b = 0; b < B; ++b) cnt += (flags[b] != 0 && ctx->spec_meta_host[b] == 0);
-        *value = cnt;
+        double acc = 0;
+        const bool have_off = ctx->offsets_host.size() == B + 1;
+        for (size_t b = 0; b < B; ++b)
+            if (flags[b] != 0 && ctx->spec_meta_host[b] == 0)
+                acc += samples ? (have_off ? (double)(ctx->offsets_host[b + 1] - ctx->offsets_host[b]) : 0.0) : 1.0;
+        *value = acc;
         return F2_OK;
     }
     const opt_entry* e = find_option(key);

@@ -7,24 +7,27 @@
 // in phases that all waves of a workgroup go through together.
 //
 // Here every wave keeps the weights of its role in registers for the whole launch (9 taps x 32 input channels x 32 outputs x 2
-// bf16 pieces = 144 VGPRs; 256 registers per wave, one 8-wave workgroup per CU, persistent over tiles), the roles of a workgroup
-// form a pipeline with ONE barrier per tile, and a wave computes two output rows so that a patch row fetched from LDS serves
-// tap row dy of one and dy - 1 of the other (48 ds_read_b128 per 108 MFMAs):
+// bf16 pieces = 144 VGPRs; 256 registers per wave, one 8-wave workgroup per CU, persistent over tiles) and the two waves of a
+// SIMD alternate: while one runs its matrix loop (one issue slot per 32 cycles) the other runs its VALU / LDS phase, ONE barrier
+// per tile. Measured with in-kernel stamps (tools/ws_stamps.py): a VALU phase beside a partner's matrix loop issues one
+// instruction per 8-10 cycles whatever the wave priorities, so the phases are counted in instructions - integer divisions,
+// per-store branches and per-tile address arithmetic are what a first version lost its time to.
 //
-//   k_conv12_ws   tile = (window, 32 conv2 columns), all 8 pooled-input rows.
-//                 waves 4-7 ("producers"): conv1 of tile t + 1 ON THE MATRIX CORES - out^T (32 channels x 32 pixels) = W1^T (32 x
-//                 16: nine taps, the bias against a constant 1, zeros) x taps^T (16 x 32 pixels), three split-bf16 MFMAs per 32
-//                 pixels; with the channels on the accumulator's row index a lane holds four consecutive channels of its pixel,
-//                 so ReLU + split + two 8-byte LDS stores per quad write the conv2 input patch ([pixel][32 channels] bf16, one
-//                 image per piece, 16-byte chunks XOR-swizzled) - no longer the oracle's fmaf chain bit for bit, held to the same
-//                 2e-5 / referee rule.
-//                 waves 0-3 ("consumers"): conv2 rows 2w, 2w + 1 of tile t from the other patch buffer, 2 x 2 max-pool in the lane
-//                 (the two rows are the wave's two accumulators), bias + ReLU, output already split in two bf16 pieces
-//                 ([window][4][W/2 - 1][hi 32 | lo 32]) so that conv3's staging is a copy.
-//   k_conv34_ws   tile = (window, 30 conv4 columns). waves 0-3: conv3 (output tile nt, row pair) of tile t + 1 from patch A into
-//                 patch B (64 channels per pixel, both pieces; accumulator rows = output channels as above); waves 4-7: first
-//                 copy tile t + 2 from HBM into the free patch A, then conv4 (output tile nt, K half) of tile t from patch B;
-//                 the K halves meet through LDS one iteration later, where the first half pools, adds the bias and stores.
+//   k_conv12_ws   tile = (window, 32 conv2 columns), all 8 conv2 rows the pool keeps. Wave w: conv2 of rows 2 (w & 3), + 1 x
+//                 columns 16 (w >> 2) .. + 15 of tile t (the 32 x 32 accumulator's row index = (row, column): the 2 x 2 max-pool
+//                 stays inside the lane), and conv1 of tile t + 1 for one or two blocks of 32 patch pixels ON THE MATRIX CORES -
+//                 out^T (32 channels x 32 pixels) = W1^T (32 x 16: nine taps, the bias against a constant 1, zeros) x taps^T (16
+//                 x 32 pixels), three split-bf16 MFMAs; with the channels on the accumulator's row index a lane holds four
+//                 consecutive channels of its pixel, so ReLU + split + two 8-byte LDS stores per quad write the conv2 input
+//                 patch ([pixel][32 channels] bf16, one image per piece, 16-byte chunks XOR-swizzled) - no longer the oracle's fmaf
+//                 chain bit for bit, held to the same 2e-5 / referee rule. Waves 0-3 run conv2 first, waves 4-7 conv1 first.
+//                 The raw input of tile t + 2 arrives by LDS-DMA (no registers, zeros outside the window from a zero buffer).
+//                 Output already split in two bf16 pieces ([window][4][W/2 - 1][hi 32 | lo 32]): conv3's staging is a copy.
+//   k_conv34_ws   tile = (window, 30 conv4 columns). waves 0-3: conv3 (output tile nt, row pair: a patch row fetched from LDS
+//                 serves tap row dy of one output row and dy - 1 of the other, 48 ds_read_b128 per 108 MFMAs) of tile t + 1 from
+//                 patch A into patch B (64 channels per pixel, both pieces; accumulator rows = output channels as above);
+//                 waves 4-7: the two K halves of tile t - 1 meet (first half: sum, pool, bias, store), tile t + 2 goes from HBM
+//                 into the free patch A by LDS-DMA, then conv4 (output tile nt, K half) of tile t from patch B.
 //
 // Layout of an MFMA operand (tools/ubench/mfma_bf16_layout.hip): lane (i, h) supplies k = 8 h .. 8 h + 7 of row / column i;
 // accumulator register q of lane (i, h) is row (q & 3) + 8 (q >> 2) + 4 h, column i.
@@ -35,19 +38,25 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C1 = 32, C2 = 32, C3 = 64, C4 = 64;
 constexpr int PW = 34;            // patch width: 32 output columns + 2
 constexpr int T34 = 30;           // conv4 output columns per tile
 
-// byte offset of 16-byte chunk `chunk` of pixel `pixel`; PIXB = bytes per pixel and piece (64: 32 channels, 128: 64 channels).
-// Sixteen consecutive pixels put any one chunk on sixteen different 16-byte slots of the 256-byte bank row: ds_read_b128 of
-// 32 consecutive pixels is conflict-free.
-template <int PIXB>
-__device__ __forceinline__ int pix_off(int pixel, int chunk) {
-    if constexpr (PIXB == 64) return pixel * 64 + ((chunk ^ ((pixel >> 2) & 3)) << 4);
-    else return pixel * 128 + ((chunk ^ ((pixel >> 1) & 7)) << 4);
-}
+// LDS images of the activation patches. A matrix step takes 16 input channels (kb = which 16) of 32 pixels: lane (i, h) reads the
+// 16 bytes of channels 16 kb + 8 h .. + 7 of its pixel. Every piece (hi / lo) of a patch is stored as PLANES of 16-channel
+// groups so that kb is a compile-time byte offset (one address register per tap instead of two), and inside a plane the
+// 16-byte chunks are XOR-swizzled so that ds_read_b128 (four groups of 16 lanes, sixteen 16-byte slots per LDS cycle) is
+// conflict-free for the access pattern of its reader (brute force: tools/lds_swizzle_check.py):
+//   32-channel patches: two planes of 32 bytes per pixel, half h at p * 32 + ((h ^ s) << 4) with
+//     s = (p >> 3) & 1   conv3's input, read 32 consecutive pixels of a row at a time                     (a32_off)
+//     s = row & 1        conv2's input, read two rows x 16 columns at a time (the pool stays in the lane)  (c32_off)
+//   64-channel patch (conv4's input): two planes of 64 bytes per pixel (channels 32 kh + 16 kb + 8 h: chunk q = 2 kh + h of plane
+//     kb) at p * 64 + ((q ^ ((p >> 2) & 3)) << 4)                                                          (b64_off)
+__device__ __forceinline__ int a32_off(int p, int h) { return p * 32 + ((h ^ ((p >> 3) & 1)) << 4); }
+__device__ __forceinline__ int c32_off(int row, int col, int h) { return (row * PW + col) * 32 + ((h ^ (row & 1)) << 4); }
+__device__ __forceinline__ int b64_off(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
 
 __device__ __forceinline__ void split4(const float v0, const float v1, const float v2, const float v3, bf16x4& hi, bf16x4& lo) {
     const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1, h2 = (__bf16)v2, h3 = (__bf16)v3;
@@ -62,28 +71,58 @@ __device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// Issue priority of this wave on its SIMD: high in the VALU / LDS phases, low in the matrix loop (which needs one issue slot per
+// 32 cycles). Measured effect: none either way (tools/ws_stamps.py); kept because it is the documented intent.
+#define PRIO_VALU() __builtin_amdgcn_s_setprio(3)
+#define PRIO_MATRIX() __builtin_amdgcn_s_setprio(0)
+
+// tile index -> (window, tile in window) without a division: q = floor(t / d) = mulhi(t, ceil(2^32 / d)) for t < 2^32 / d
+struct tile_div {
+    unsigned d, mul;
+};
+__device__ __forceinline__ void tile_split(unsigned t, tile_div td, unsigned& q, unsigned& r) {
+    q = td.d == 1 ? t : __umulhi(t, td.mul);
+    r = t - q * td.d;
+}
+
+// Diagnostic build (-DF2_WS_STAMPS, tools/build_variant.sh): s_memtime at phase boundaries of iterations 8 .. 39 of the first
+// eight workgroups, [workgroup][wave][iteration][slot]; slot 7 = s_memrealtime at the start of the iteration (clock estimate).
+#ifdef F2_WS_STAMPS
+#define WS_STAMP_ARG , unsigned long long* stamps
+#define WS_STAMP(it, slot)                                                                                              \
+    do {                                                                                                                \
+        if (stamps && blockIdx.x < 8 && (it) >= 8 && (it) < 40 && lane == 0) {                                          \
+            unsigned long long* sp_ = stamps + ((((size_t)blockIdx.x * 8 + wave) * 32 + ((it) - 8)) * 8);               \
+            sp_[slot] = __builtin_amdgcn_s_memtime();                                                                   \
+            if ((slot) == 0) sp_[7] = __builtin_amdgcn_s_memrealtime();                                                 \
+        }                                                                                                               \
+    } while (0)
+#else
+#define WS_STAMP_ARG
+#define WS_STAMP(it, slot)
+#endif
 
 // Two output rows x 32 columns x 32 output channels of a 3 x 3 convolution over 32 input channels (18 steps of 16): the
 // patch rows r0 .. r0 + 3 are fetched once (hi and lo piece of (pixel, 16 channels): two ds_read_b128), row pr serving tap row
-// dy = pr of output row 0 and dy = pr - 1 of output row 1. SWAP: the weights are the A operand (accumulator rows = output
-// channels, columns = pixels), otherwise the B operand (rows = pixels, columns = output channels).
-template <int PIXB, bool SWAP>
+// dy = pr of output row 0 and dy = pr - 1 of output row 1. off(pr, dx) = byte offset of this lane's 16 bytes in plane 0 for patch
+// row pr, tap column dx; PLANE = bytes between the two 16-channel planes. SWAP: the weights are the A operand (accumulator rows =
+// output channels, columns = pixels), otherwise the B operand (rows = pixels, columns = output channels).
+template <bool SWAP, int DEPTH, int PLANE, class OFF>
 __device__ __forceinline__ void conv_two_rows(f32x16 (&acc)[2], const bf16x8 (&wh)[18], const bf16x8 (&wl)[18],
-                                              const unsigned char* ph, const unsigned char* pl, int pix0, int chunk0) {
-    constexpr int NF = 24, DEPTH = 3;
+                                              const unsigned char* ph, const unsigned char* pl, OFF off) {
+    constexpr int NF = 24;
     bf16x8 fh[DEPTH], fl[DEPTH];
-    // chunk0 has bit 1 clear, so the second 16-channel block of a pixel (chunk0 + 2) sits at the first one's offset ^ 32
     auto fetch = [&](int f, int slot) {
         const int pr = f / 6, dx = (f >> 1) % 3, kb = f & 1;
-        const int off = pix_off<PIXB>(pix0 + pr * PW + dx, chunk0) ^ (kb << 5);
-        fh[slot] = *reinterpret_cast<const bf16x8*>(ph + off);
-        fl[slot] = *reinterpret_cast<const bf16x8*>(pl + off);
+        const int o = off(pr, dx) + kb * PLANE;
+        fh[slot] = *reinterpret_cast<const bf16x8*>(ph + o);
+        fl[slot] = *reinterpret_cast<const bf16x8*>(pl + o);
     };
-    fetch(0, 0);
-    fetch(1, 1);
+#pragma unroll
+    for (int f = 0; f < DEPTH - 1; ++f) fetch(f, f);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        if (f + 2 < NF) fetch(f + 2, (f + 2) % DEPTH);
+        if (f + DEPTH - 1 < NF) fetch(f + DEPTH - 1, (f + DEPTH - 1) % DEPTH);
         __builtin_amdgcn_sched_barrier(0);
         const int s = f % DEPTH, pr = f / 6, dx = (f >> 1) % 3, kb = f & 1;
         if (pr <= 2) {
@@ -114,174 +153,243 @@ __device__ __forceinline__ void conv_two_rows(f32x16 (&acc)[2], const bf16x8 (&w
     }
 }
 
+// One 32 x 32 accumulator of the same convolution: off(dy, dx) = byte offset in plane 0 of this lane's pixel for tap (dy, dx);
+// 18 steps, two ds_read_b128 + three MFMAs each, DEPTH - 1 steps requested ahead.
+template <int DEPTH, int PLANE, class OFF>
+__device__ __forceinline__ void conv_one_tile(f32x16& acc, const bf16x8 (&wh)[18], const bf16x8 (&wl)[18],
+                                              const unsigned char* ph, const unsigned char* pl, OFF off) {
+    constexpr int NF = 18;
+    bf16x8 fh[DEPTH], fl[DEPTH];
+    auto fetch = [&](int f, int slot) {
+        const int tap = f >> 1, kb = f & 1, dy = tap / 3, dx = tap - 3 * dy;
+        const int o = off(dy, dx) + kb * PLANE;
+        fh[slot] = *reinterpret_cast<const bf16x8*>(ph + o);
+        fl[slot] = *reinterpret_cast<const bf16x8*>(pl + o);
+    };
+#pragma unroll
+    for (int f = 0; f < DEPTH - 1; ++f) fetch(f, f);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        if (f + DEPTH - 1 < NF) fetch(f + DEPTH - 1, (f + DEPTH - 1) % DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        const int s = f % DEPTH;
+        acc = MFMA16(fl[s], wh[f], acc);
+        acc = MFMA16(fh[s], wl[f], acc);
+        acc = MFMA16(fh[s], wh[f], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // conv1 + conv2 + pool
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int P12_ROWS = 10;                       // conv1 rows 0 .. 9 feed conv2 rows 0 .. 7 (the ninth conv2 row is dropped by the pool)
 constexpr int P12_PIX = P12_ROWS * PW;             // 340 patch pixels
-constexpr int P12_PIECE = P12_PIX * 64;            // bytes per piece
+constexpr int P12_PLANE = P12_PIX * 32;            // one 16-channel plane of a piece
+constexpr int P12_PIECE = 2 * P12_PLANE;           // bytes per piece
 constexpr int P12_BUF = 2 * P12_PIECE;             // hi + lo
-constexpr int P12_TILES = (P12_PIX + 31) / 32;     // 11 conv1 tiles of 32 pixels
-constexpr int P12_TPW = (P12_TILES + 3) / 4;       // per producer wave
+constexpr int P12_TILES = (P12_PIX + 31) / 32;     // 11 conv1 blocks of 32 pixels: wave w takes block w, waves 0-2 also block 8 + w
 constexpr int XR = P12_ROWS + 2, XW = PW + 2;      // raw input region of a task: rows -1 .. 10, columns x0 - 1 .. x0 + 34
 constexpr int XIN = XR * XW;                       // 432 floats
-constexpr int XIN_DMA = (XIN + 63) / 64;           // 256-byte LDS-DMA pieces
+static_assert((XIN + 63) / 64 == 7, "LDS-DMA pieces of the raw input: waves 3-7 take piece w - 3, waves 3, 4 also w + 2");
 constexpr int XIN_BYTES = ((XIN * 4 + 255) / 256) * 256;
-constexpr size_t LDS12 = 2 * (size_t)XIN_BYTES + 2 * (size_t)P12_BUF;   // two raw-input buffers (first: LDS-DMA targets), two patch buffers
+constexpr int CTAB = 2 * XW + 2;                   // floats: 1, 0, 0, ... - what the upper lane half reads in place of taps 1 .. 7,
+constexpr int CTAB_BYTES = ((CTAB * 4 + 255) / 256) * 256;   // one copy behind EACH raw-input buffer (same offset from either base)
+constexpr int XIN_STRIDE = XIN_BYTES + CTAB_BYTES;
+constexpr size_t LDS12 = 2 * (size_t)XIN_STRIDE + 2 * (size_t)P12_BUF;   // (raw input + table) x 2 (LDS-DMA targets first), patches x 2
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-// global -> LDS without registers (global_load_lds_dword / _dwordx4): the LDS address is `l` + lane x SIZE, `l` wave-uniform
-__device__ __forceinline__ void dma4_to_lds(const void* g, void* l) { __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 4, 0, 0); }
-__device__ __forceinline__ void dma16_to_lds(const void* g, void* l) { __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); }
+// global -> LDS without registers (global_load_lds_dword / _dwordx4; LDS address = `lds_addr` + lane x size, wave-uniform), as
+// inline asm: with the builtin in the kernel, hipcc (ROCm 7.2) stops counting LDS reads and waits `lgkmcnt(0)` in front of the
+// MFMAs - the fragment just requested included - which took the matrix loops from 34 to 52 cycles per MFMA. Hidden from the
+// compiler, the loads are waited for by hand: dma_wait() before the barrier that hands the buffer over.
+__device__ __forceinline__ unsigned lds_address(const void* p) { return (unsigned)(uintptr_t)(lds_ptr_t)p; }
+__device__ __forceinline__ void dma4_to_lds(const void* g, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma16_to_lds(const void* g, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Per iteration k of a workgroup (its tasks t_0, t_1, ...; ONE barrier per iteration):
-//   producers  raw input of t_(k+2): HBM -> LDS by LDS-DMA (zeros outside the window come from a zero buffer);
-//              conv1 of t_(k+1) from the raw input that landed an iteration ago -> patch buffer (k + 1) & 1
-//   consumers  conv2 + pool of t_k from patch buffer k & 1
+// Per iteration k of a workgroup (its tasks t_0, t_1, ...; ONE barrier per iteration), every wave:
+//   conv2 + pool of its 2 x 16 pixels of t_k from patch buffer k & 1                                   (matrix loop)
+//   conv1 of its one or two pixel blocks of t_(k+1), from the raw input that landed an iteration ago, into patch buffer
+//   (k + 1) & 1; its pieces of the raw input of t_(k+2): HBM -> LDS by LDS-DMA                         (VALU / LDS phase)
+// waves 0-3 in this order, waves 4-7 (their partners on the SIMDs) the other way round.
 __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, const float* __restrict__ w1,
                                                    const float* __restrict__ b1, const bf16x8* __restrict__ w2s,
                                                    const float* __restrict__ b2, __bf16* __restrict__ out,
-                                                   const float* __restrict__ zeros, int Hin, int Win, int xtiles, int64_t ntask) {
+                                                   const float* __restrict__ zeros, int Hin, int Win, int Wa, tile_div xt,
+                                                   unsigned ntask WS_STAMP_ARG) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* const ldsP = lds + 2 * XIN_BYTES;
+    unsigned char* const ldsP = lds + 2 * XIN_STRIDE;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: roles, LDS-DMA targets)
     const int i = lane & 31, h = lane >> 5;
-    const int Wout = (Win - 2) / 2;
-    const int64_t G = gridDim.x;
-    const int64_t nloc = (ntask - blockIdx.x + G - 1) / G;     // tasks of this workgroup: blockIdx.x + k G
+    const unsigned G = gridDim.x;
+    const int nloc = (int)((ntask - blockIdx.x + G - 1) / G);  // tasks of this workgroup: blockIdx.x + k G
+    const int rp = wave & 3, ch = wave >> 2;
 
-    if (wave < 4) {
-        // ---------------- consumers: conv2 rows 2 wave, 2 wave + 1 ----------------
-        bf16x8 wh[18], wl[18];
-        {
-            const bf16x8* ph = w2s + h * C2 + i;               // [piece][tap][kb][h][cout]
-            const bf16x8* pl = ph + 18 * 2 * C2;
+    if (threadIdx.x < 2 * CTAB) {
+        const int b = threadIdx.x >= CTAB ? 1 : 0, e = threadIdx.x - b * CTAB;
+        reinterpret_cast<float*>(lds + b * XIN_STRIDE + XIN_BYTES)[e] = e == 0 ? 1.f : 0.f;
+    }
+
+    // conv2 weights of every wave: B operand, [piece][tap][kb][h][cout]
+    bf16x8 wh[18], wl[18];
+    {
+        const bf16x8* ph = w2s + h * C2 + i;
+        const bf16x8* pl = ph + 18 * 2 * C2;
 #pragma unroll
-            for (int st = 0; st < 18; ++st) {
-                wh[st] = ph[st * 2 * C2];
-                wl[st] = pl[st * 2 * C2];
-            }
-#pragma unroll
-            for (int st = 0; st < 18; ++st) {
-                pin(wh[st]);
-                pin(wl[st]);
-            }
+        for (int st = 0; st < 18; ++st) {
+            wh[st] = ph[st * 2 * C2];
+            wl[st] = pl[st * 2 * C2];
         }
-        const float bias = b2[i];
-        for (int64_t k = -2; k < nloc; ++k) {
-            if (k >= 0) {
-                const int64_t t = blockIdx.x + k * G;
-                const int64_t win = t / xtiles;
-                const int x0 = 32 * (int)(t - win * xtiles);
-                const unsigned char* ph = ldsP + (k & 1) * P12_BUF;
-                f32x16 acc[2];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    acc[0][q] = 0.f;
-                    acc[1][q] = 0.f;
-                }
-                conv_two_rows<64, false>(acc, wh, wl, ph, ph + P12_PIECE, (2 * wave) * PW + i, h);
-                // 2 x 2 pool inside the lane: register pair (q, q + 1) = columns (2 t, 2 t + 1), the two accumulators = the two rows
-                __bf16* o = out + ((win * 4 + wave) * (int64_t)Wout) * 64 + i;
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const int q = 2 * kk;
-                    const int px = (x0 + (q & 3) + 8 * (q >> 2) + 4 * h) >> 1;
-                    const float m = fmaxf(fmaxf(acc[0][q], acc[0][q + 1]), fmaxf(acc[1][q], acc[1][q + 1]));
-                    const float v = fmaxf(m + bias, 0.f);
-                    const __bf16 vh = (__bf16)v;
-                    const __bf16 vl = (__bf16)(v - (float)vh);
-                    if (px < Wout) {
-                        o[(int64_t)px * 64] = vh;
-                        o[(int64_t)px * 64 + 32] = vl;
-                    }
-                }
-            }
-            __syncthreads();
+        for (int st = 0; st < 18; ++st) {
+            pin(wh[st]);
+            pin(wl[st]);
         }
-    } else {
-        // ---------------- producers ----------------
-        const int pw = wave - 4;
-        // W1^T as the A operand: row = channel i, k = tap (0..8), 9 = bias (times a constant 1), 10..15 = 0
-        bf16x8 w1h, w1l;
+    }
+    float bias = b2[i];
+    asm volatile("" : "+v"(bias));         // (settled here: a load still "pending" at the loop head costs a vmcnt wait in front of every store)
+    // W1^T as the A operand: row = channel i, k = tap (0..8), 9 = bias (times a constant 1), 10..15 = 0
+    bf16x8 w1h, w1l;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int tap = 8 * h + j;
-            const float v = tap < 9 ? w1[(tap < 9 ? tap : 0) * C1 + i] : tap == 9 ? b1[i] : 0.f;
-            const __bf16 vh = (__bf16)v;
-            w1h[j] = vh;
-            w1l[j] = (__bf16)(v - (float)vh);
-        }
-        pin(w1h);
-        pin(w1l);
-        for (int64_t k = -2; k < nloc; ++k) {
-            if (k + 2 < nloc) {
-                // raw input region of task t_(k+2): element e = (row r, column c) of the 12 x 36 region, one dword per lane
-                const int64_t t = blockIdx.x + (k + 2) * G;
-                const int64_t win = t / xtiles;
-                const int x0 = 32 * (int)(t - win * xtiles);
-                const float* img = x + win * (int64_t)Hin * Win;
-                unsigned char* xb = lds + (k & 1) * XIN_BYTES;
+    for (int j = 0; j < 8; ++j) {
+        const int tap = 8 * h + j;
+        const float v = tap < 9 ? w1[(tap < 9 ? tap : 0) * C1 + i] : tap == 9 ? b1[i] : 0.f;
+        const __bf16 vh = (__bf16)v;
+        w1h[j] = vh;
+        w1l[j] = (__bf16)(v - (float)vh);
+    }
+    pin(w1h);
+    pin(w1l);
+
+    // conv2: this lane's pixel (accumulator row i): image row 2 rp + (i >> 4), column 16 ch + (i & 15)
+    const int row2 = 2 * rp + (i >> 4), col2 = 16 * ch + (i & 15);
+    // conv1: pixel e of block b is patch pixel 32 b + i; lane (i, h) supplies taps 8 h + j: the lower half reads taps 0 .. 7 at
+    // xin[(pr + dy) XW + pc + dx], the upper half tap 8 and then the table 1, 0, 0, ... through the same immediate offsets
+    int xoff0[2], xoff1[2], poff[2];       // byte offsets: tap slot 0, tap slots 1..7 (from xin[0]), patch pixel
 #pragma unroll
-                for (int m = 0; m < (XIN_DMA + 3) / 4; ++m) {
-                    const int piece = pw + 4 * m;              // wave-uniform
-                    if (piece < XIN_DMA) {
-                        const int e = 64 * piece + lane;
-                        const int r = e / XW, c = e - r * XW;
-                        const int yi = r - 1, xi = x0 - 1 + c;
-                        const float* src = (yi >= 0 && yi < Hin && xi >= 0 && xi < Win) ? img + yi * Win + xi : zeros;
-                        if (e < XIN) dma4_to_lds(src, xb + 256 * piece);
-                    }
+    for (int tt = 0; tt < 2; ++tt) {
+        const int e = 32 * (wave + 8 * tt) + i, ec = min(e, P12_PIX - 1);
+        const int pr = ec / PW, pc = ec - pr * PW;
+        xoff0[tt] = (pr * XW + pc + (h ? 2 * XW + 2 : 0)) * 4;
+        xoff1[tt] = h ? XIN_BYTES - 4 : (pr * XW + pc) * 4;           // (upper half: table[-1], so that slot j = 1 reads table[0])
+        poff[tt] = e < P12_PIX ? c32_off(pr, pc, 0) + 8 * h : -1;       // channels 8 g + 4 h ..: plane g >> 1, at poff ^ ((g & 1) << 4)
+    }
+    const int nblk = wave + 8 < P12_TILES ? 2 : 1;
+    // LDS-DMA pieces of this wave (wave-uniform)
+    const int dma0 = wave >= 3 ? wave - 3 : -1, dma1 = (wave == 3 || wave == 4) ? wave + 2 : -1;
+    __syncthreads();
+
+    auto vphase = [&](int k) {
+        if (k + 2 < nloc && dma0 >= 0) {
+            // raw input region of task t_(k+2): element e = (row r, column c) of the 12 x 36 region, one dword per lane
+            unsigned win, xi0;
+            tile_split(blockIdx.x + (unsigned)(k + 2) * G, xt, win, xi0);
+            const int x0 = 32 * (int)xi0;
+            const float* img = x + (size_t)win * (size_t)(Hin * Win);
+            const unsigned xb = __builtin_amdgcn_readfirstlane(lds_address(lds) + (k & 1) * XIN_STRIDE);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int piece = m == 0 ? dma0 : dma1;
+                if (piece >= 0) {
+                    const int e = 64 * piece + lane;
+                    const int r = e / XW, c = e - r * XW;
+                    const int yi = r - 1, xi = x0 - 1 + c;
+                    const float* src = ((unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win) ? img + yi * Win + xi : zeros;
+                    if (e < XIN) dma4_to_lds(src, __builtin_amdgcn_readfirstlane(xb + 256 * piece));
                 }
             }
-            if (k + 1 >= 0 && k + 1 < nloc) {
-                // conv1 of task t_(k+1): lane (i, h) supplies taps 8 h + j of pixel 32 tile + i
-                const float* xin = reinterpret_cast<const float*>(lds + ((k + 1) & 1) * XIN_BYTES);
-                unsigned char* ph = ldsP + ((k + 1) & 1) * P12_BUF;
-                unsigned char* pl = ph + P12_PIECE;
+        }
+        if (k + 1 >= 0 && k + 1 < nloc) {
+            const unsigned char* xin = lds + ((k + 1) & 1) * XIN_STRIDE;
+            unsigned char* ph = ldsP + ((k + 1) & 1) * P12_BUF;
 #pragma unroll
-                for (int tt = 0; tt < P12_TPW; ++tt) {
-                    const int tile = pw + 4 * tt;
-                    if (tile >= P12_TILES) continue;           // wave-uniform
-                    const int e = 32 * tile + i;
-                    const int ec = min(e, P12_PIX - 1);
-                    const int pr = ec / PW, pc = ec - pr * PW;
-                    const float* xp = xin + pr * XW + pc;      // taps (dy, dx) at xp[dy * XW + dx]
-                    float xv[8];
-                    xv[0] = xp[h ? 2 * XW + 2 : 0];            // tap 0, or tap 8 in the upper half
+            for (int tt = 0; tt < 2; ++tt) {
+                if (tt >= nblk) continue;                      // wave-uniform
+                const float* x0p = reinterpret_cast<const float*>(xin + xoff0[tt]);
+                const float* x1p = reinterpret_cast<const float*>(xin + xoff1[tt]);
+                float xv[8];
+                xv[0] = x0p[0];
 #pragma unroll
-                    for (int j = 1; j < 8; ++j) {
-                        const float v = xp[(j / 3) * XW + (j % 3)];
-                        xv[j] = h ? (j == 1 ? 1.f : 0.f) : v;  // upper half: the bias slot, then zeros
-                    }
-                    bf16x8 xh, xl;
+                for (int j = 1; j < 8; ++j) xv[j] = x1p[(j / 3) * XW + (j % 3)];
+                bf16x8 xh, xl;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const __bf16 vh = (__bf16)xv[j];
-                        xh[j] = vh;
-                        xl[j] = (__bf16)(xv[j] - (float)vh);
-                    }
-                    f32x16 a;
+                for (int j = 0; j < 8; ++j) {
+                    const __bf16 vh = (__bf16)xv[j];
+                    xh[j] = vh;
+                    xl[j] = (__bf16)(xv[j] - (float)vh);
+                }
+                f32x16 a;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) a[q] = 0.f;
-                    a = MFMA16(w1l, xh, a);
-                    a = MFMA16(w1h, xl, a);
-                    a = MFMA16(w1h, xh, a);
-                    if (e < P12_PIX) {
+                for (int q = 0; q < 16; ++q) a[q] = 0.f;
+                a = MFMA16(w1l, xh, a);
+                a = MFMA16(w1h, xl, a);
+                a = MFMA16(w1h, xh, a);
+                if (poff[tt] >= 0) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {          // channels 8 g + 4 h .. + 3 of pixel e
-                            bf16x4 vh, vl;
-                            split4(relu(a[4 * g]), relu(a[4 * g + 1]), relu(a[4 * g + 2]), relu(a[4 * g + 3]), vh, vl);
-                            const int off = pix_off<64>(e, g) + 8 * h;
-                            *reinterpret_cast<bf16x4*>(ph + off) = vh;
-                            *reinterpret_cast<bf16x4*>(pl + off) = vl;
-                        }
+                    for (int g = 0; g < 4; ++g) {              // channels 8 g + 4 h .. + 3 of the pixel
+                        bf16x4 vh, vl;
+                        split4(relu(a[4 * g]), relu(a[4 * g + 1]), relu(a[4 * g + 2]), relu(a[4 * g + 3]), vh, vl);
+                        const int off = (g >> 1) * P12_PLANE + (poff[tt] ^ ((g & 1) << 4));
+                        *reinterpret_cast<bf16x4*>(ph + off) = vh;
+                        *reinterpret_cast<bf16x4*>(ph + P12_PIECE + off) = vl;
                     }
                 }
             }
-            __syncthreads();
         }
+    };
+
+    for (int k = -2; k < nloc; ++k) {
+        WS_STAMP(k, 0);
+        if (wave >= 4) vphase(k);
+        WS_STAMP(k, 4);
+        if (k >= 0) {
+            unsigned win, xi0;
+            tile_split(blockIdx.x + (unsigned)k * G, xt, win, xi0);
+            const int x0 = 32 * (int)xi0 + 16 * ch;
+            const unsigned char* ph = ldsP + (k & 1) * P12_BUF;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            PRIO_MATRIX();
+            conv_one_tile<4, P12_PLANE>(acc, wh, wl, ph, ph + P12_PIECE, [&](int dy, int dx) { return c32_off(row2 + dy, col2 + dx, h); });
+            PRIO_VALU();
+            if (wave >= 4) dma_wait();                        // (its LDS-DMA of this iteration, issued a matrix loop ago; before the stores)
+            WS_STAMP(k, 1);
+            // 2 x 2 pool inside the lane: registers q, q + 1 = columns 2 t, 2 t + 1 of the first row, q + 8, q + 9 of the second.
+            // The output rows have a pitch of Wa = 16 x tiles pixels, so every lane's four pixels exist (columns past the image
+            // land in the padding, which conv3's loader never reads): no bounds tests, one address, immediate offsets.
+            __bf16* o = out + ((size_t)(win * 4 + rp) * (size_t)Wa + (size_t)((x0 >> 1) + 2 * h)) * 64 + i;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int q = 2 * kk;
+                const int dpx = ((q & 3) + 8 * (q >> 2)) >> 1;                     // 0, 1, 4, 5
+                const float m = fmaxf(fmaxf(acc[q], acc[q + 1]), fmaxf(acc[q + 8], acc[q + 9]));
+                const float v = relu(m + bias);
+                const __bf16 vh = (__bf16)v;
+                const __bf16 vl = (__bf16)(v - (float)vh);
+                o[dpx * 64] = vh;
+                o[dpx * 64 + 32] = vl;
+            }
+        }
+        WS_STAMP(k, 2);
+        if (wave < 4) {
+            vphase(k);
+            dma_wait();
+        } else if (k < 0) {
+            dma_wait();                                       // (the first two iterations have no matrix loop to wait behind)
+        }
+        WS_STAMP(k, 5);
+        __syncthreads();
+        WS_STAMP(k, 3);
     }
 }
 
@@ -289,14 +397,17 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
 // conv3 + conv4 + pool
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int PA_PIX = 6 * PW;                     // conv3 input patch: pooled conv2 rows -1 .. 4, columns c0 - 1 .. c0 + 32
-constexpr int PA_PIECE = PA_PIX * 64;
+constexpr int PA_PLANE = PA_PIX * 32;
+constexpr int PA_PIECE = 2 * PA_PLANE;
 constexpr int PA_BUF = 2 * PA_PIECE;
 constexpr int PB_PIX = 4 * PW;                     // conv4 input patch: conv3 rows 0 .. 3, columns c0 .. c0 + 33
-constexpr int PB_PIECE = PB_PIX * 128;
+constexpr int PB_PLANE = PB_PIX * 64;
+constexpr int PB_PIECE = 2 * PB_PLANE;
 constexpr int PB_BUF = 2 * PB_PIECE;
 constexpr int X_BUF = 2 * 8 * 64 * 16;             // partial sums of the second K half: 2 output tiles x 8 register quads x 64 lanes x 16 B
 constexpr int PA_CHUNKS = 2 * PA_PIX * 4;          // 16-byte chunks of a patch A buffer
 constexpr int PA_DMA = (PA_CHUNKS + 63) / 64;      // 1 KB LDS-DMA pieces of a patch A buffer
+constexpr int PA_DMA_PER_WAVE = (PA_DMA + 3) / 4;  // 7
 constexpr int BIAS3_BYTES = 2 * 2 * 16 * 4;        // conv3 biases in accumulator order: [output tile][lane half][register]
 constexpr size_t LDS34 = 2 * (size_t)PA_BUF + 2 * (size_t)PB_BUF + 2 * (size_t)X_BUF + BIAS3_BYTES;
 static_assert(LDS34 <= 160 * 1024, "one workgroup per CU");
@@ -304,7 +415,7 @@ static_assert(LDS34 <= 160 * 1024, "one workgroup per CU");
 __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in, const bf16x8* __restrict__ w3s,
                                                    const float* __restrict__ b3, const bf16x8* __restrict__ w4s,
                                                    const float* __restrict__ b4, float* __restrict__ out,
-                                                   const uint4* __restrict__ zeros, int Win, int xtiles, int64_t ntile) {
+                                                   const uint4* __restrict__ zeros, int Win, int Wa, tile_div xt, unsigned ntile WS_STAMP_ARG) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + 2 * PA_BUF;
@@ -313,9 +424,8 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int Wp = (Win - 2) / 2;                             // pooled conv4 width
-    const int64_t G = gridDim.x;
-    // tiles of this workgroup: blockIdx.x + j G, j = 0 .. nloc - 1
-    const int64_t nloc = (ntile - blockIdx.x + G - 1) / G;
+    const unsigned G = gridDim.x;
+    const int nloc = (int)((ntile - blockIdx.x + G - 1) / G); // tiles of this workgroup: blockIdx.x + j G
 
     // the columns of patch B that only conv4's discarded outputs read are never written: clear both buffers once
     for (int e = tid; e < (int)(2 * PB_BUF / 16); e += 512) reinterpret_cast<uint4*>(ldsB)[e] = make_uint4(0u, 0u, 0u, 0u);
@@ -340,36 +450,81 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
                 pin(wl[st]);
             }
         }
-        const float4* bias4 = reinterpret_cast<const float4*>(ldsBias + (nt * 2 + h) * 16);   // (16 registers too many to hold)
-        for (int64_t j = -2; j <= nloc; ++j) {
-            const int64_t jt = j + 1;                         // conv3 works one tile ahead of conv4
-            if (jt >= 0 && jt < nloc) {
-                const unsigned char* pa = ldsA + (jt & 1) * PA_BUF;
-                unsigned char* pbh = ldsB + (jt & 1) * PB_BUF;
-                unsigned char* pbl = pbh + PB_PIECE;
-                f32x16 acc[2];
+        const f32x4* bias4 = reinterpret_cast<const f32x4*>(ldsBias + (nt * 2 + h) * 16);   // (16 registers too many to hold)
+        // LDS-DMA pieces of this wave, once: 16-byte slot s = 64 piece + lane of a patch A buffer = (piece, pixel, position) <-
+        // chunk (position ^ swizzle(pixel)) of that pixel's piece (the XOR is its own inverse: the readers apply the same one).
+        // rel = the chunk's index relative to (window, column c0 - 1) of the input; pcx = the pixel's patch column, or a value no
+        // image is wide enough for where the patch row lies outside the image (rows -1 and 4) or the slot does not exist
+        // (one register per piece: rel in bits 0 .. 23, pcx in bits 24 .. 31, 255 = never inside; f2_cnn_ws_supported bounds the width)
+        unsigned relpc[PA_DMA_PER_WAVE];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    acc[0][q] = 0.f;
-                    acc[1][q] = 0.f;
-                }
-                conv_two_rows<64, true>(acc, wh, wl, pa, pa + PA_PIECE, (2 * rp) * PW + i, h);
+        for (int m = 0; m < PA_DMA_PER_WAVE; ++m) {
+            const int sl = 64 * (wave + 4 * m) + lane;
+            // slot = (piece, plane kb, pixel, position): the 16 bytes of channels 16 kb + 8 (position ^ s(pixel)) of that pixel's piece
+            const int piece = sl >= PA_PIX * 4 ? 1 : 0, rem = sl - piece * (PA_PIX * 4);
+            const int kb = rem >= PA_PIX * 2 ? 1 : 0, rem2 = rem - kb * (PA_PIX * 2);
+            const int pixel = rem2 >> 1, c = 2 * kb + ((rem2 & 1) ^ ((pixel >> 3) & 1));
+            const int r = pixel / PW, pc = pixel - r * PW;
+            const bool inside = sl < PA_CHUNKS && r >= 1 && r <= 4;
+            relpc[m] = inside ? (unsigned)(((r - 1) * Wa + pc) * 8 + piece * 4 + c) | ((unsigned)pc << 24) : 0xFF000000u;
+            asm volatile("" : "+v"(relpc[m]));
+        }
+        for (int j = -2; j <= nloc; ++j) {
+            WS_STAMP(j, 0);
+            // tile j + 2 from HBM into the patch A buffer this wave's matrix loop read in the PREVIOUS iteration, by LDS-DMA (this
+            // iteration's loop read the other one); pixels outside the image come from the zero buffer
+            if (j + 2 < nloc) {
+                unsigned win, xi0;
+                tile_split(blockIdx.x + (unsigned)(j + 2) * G, xt, win, xi0);
+                const int cm1 = T34 * (int)xi0 - 1;                   // image column of patch column 0
+                const unsigned pa = __builtin_amdgcn_readfirstlane(lds_address(ldsA) + (j & 1) * PA_BUF);
+                const uint4* img = in + ((size_t)win * 4 * (size_t)Wa + cm1) * 8;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int pb = (2 * rp + mt) * PW + i;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {             // channels 32 nt + 8 g + 4 h .. + 3 of pixel pb
-                        bf16x4 vh, vl;
-                        const float4 bq = bias4[g];
-                        split4(relu(acc[mt][4 * g] + bq.x), relu(acc[mt][4 * g + 1] + bq.y), relu(acc[mt][4 * g + 2] + bq.z),
-                               relu(acc[mt][4 * g + 3] + bq.w), vh, vl);
-                        const int off = pix_off<128>(pb, nt * 4 + g) + 8 * h;
-                        *reinterpret_cast<bf16x4*>(pbh + off) = vh;
-                        *reinterpret_cast<bf16x4*>(pbl + off) = vl;
+                for (int m = 0; m < PA_DMA_PER_WAVE; ++m) {
+                    const int dp = wave + 4 * m;                // wave-uniform
+                    if (dp < PA_DMA) {
+                        const uint4* src = (unsigned)(cm1 + (int)(relpc[m] >> 24)) < (unsigned)Win ? img + (relpc[m] & 0xFFFFFFu) : zeros;
+                        if (dp < PA_DMA - 1 || lane < PA_CHUNKS - 64 * (PA_DMA - 1)) dma16_to_lds(src, __builtin_amdgcn_readfirstlane(pa + 1024 * dp));
                     }
                 }
             }
+            const int jt = j + 1;                             // conv3 works one tile ahead of conv4
+            if (jt >= 0 && jt < nloc) {
+                const unsigned char* pa = ldsA + (jt & 1) * PA_BUF;
+                unsigned char* pbh = ldsB + (jt & 1) * PB_BUF;
+                // the accumulators start from the biases (four 16-byte LDS reads per row instead of 32 additions at the end)
+                f32x16 acc[2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bq = bias4[g];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][4 * g + r] = bq[r];
+                        acc[1][4 * g + r] = bq[r];
+                    }
+                }
+                PRIO_MATRIX();
+                conv_two_rows<true, 3, PA_PLANE>(acc, wh, wl, pa, pa + PA_PIECE, [&](int pr, int dx) { return a32_off((2 * rp + pr) * PW + i + dx, h); });
+                PRIO_VALU();
+                WS_STAMP(j, 1);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int pb = (2 * rp + mt) * PW + i;
+                    const int base = b64_off(pb, 2 * nt) + 8 * h;   // chunk 2 nt + (g & 1) of plane g >> 1: base ^ ((g & 1) << 4)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {             // channels 32 nt + 8 g + 4 h .. + 3 of pixel pb
+                        bf16x4 vh, vl;
+                        split4(relu(acc[mt][4 * g]), relu(acc[mt][4 * g + 1]), relu(acc[mt][4 * g + 2]), relu(acc[mt][4 * g + 3]), vh, vl);
+                        const int off = (g >> 1) * PB_PLANE + (base ^ ((g & 1) << 4));
+                        *reinterpret_cast<bf16x4*>(pbh + off) = vh;
+                        *reinterpret_cast<bf16x4*>(pbh + PB_PIECE + off) = vl;
+                    }
+                }
+            }
+            dma_wait();                                       // (issued a matrix loop and an epilogue ago)
+            WS_STAMP(j, 2);
             __syncthreads();
+            WS_STAMP(j, 3);
         }
     } else {
         // ---------------- loader + conv4: output tile nt, K half kh (input channels 32 kh .. 32 kh + 31) ----------------
@@ -390,64 +545,42 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
                 pin(wl[st]);
             }
         }
-        const float bias = b4[nt * 32 + i];
+        float bias = b4[nt * 32 + i];
+        asm volatile("" : "+v"(bias));     // (settled here: see k_conv12_ws)
         f32x16 acc[2];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             acc[0][q] = 0.f;
             acc[1][q] = 0.f;
         }
-        for (int64_t j = -2; j <= nloc; ++j) {
+        for (int j = -2; j <= nloc; ++j) {
+            WS_STAMP(j, 0);
             // (1) first K half: the partial sums the second half left in LDS an iteration ago complete tile j - 1
             if (kh == 0 && j - 1 >= 0 && j - 1 < nloc) {
-                const int64_t tile = blockIdx.x + (j - 1) * G;
-                const int64_t win = tile / xtiles;
-                const int c0 = T34 * (int)(tile - win * xtiles);
-                const uint4* xs = reinterpret_cast<const uint4*>(ldsX + ((j - 1) & 1) * X_BUF) + nt * (8 * 64) + lane;
+                unsigned win, xi0;
+                tile_split(blockIdx.x + (unsigned)(j - 1) * G, xt, win, xi0);
+                const int c0 = T34 * (int)xi0;
+                const f32x4* xs = reinterpret_cast<const f32x4*>(ldsX + ((j - 1) & 1) * X_BUF) + nt * (8 * 64) + lane;
 #pragma unroll
                 for (int r4 = 0; r4 < 8; ++r4) {
-                    const uint4 v = xs[r4 * 64];
+                    const f32x4 v = xs[r4 * 64];
                     const int mt = r4 >> 2, q = 4 * (r4 & 3);
-                    acc[mt][q] += __uint_as_float(v.x);
-                    acc[mt][q + 1] += __uint_as_float(v.y);
-                    acc[mt][q + 2] += __uint_as_float(v.z);
-                    acc[mt][q + 3] += __uint_as_float(v.w);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][q + r] += v[r];
+                    if ((r4 & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // (two reads in flight, not eight: registers)
                 }
-                float* o = out + win * (int64_t)Wp * C4 + nt * 32 + i;
+                float* o = out + (size_t)win * (size_t)(Wp * C4) + nt * 32 + i;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int q = 2 * k;
                     const int xl = (q & 3) + 8 * (q >> 2) + 4 * h;    // even conv4 column inside the tile
                     const int pxp = (c0 + xl) >> 1;
                     const float m = fmaxf(fmaxf(acc[0][q], acc[0][q + 1]), fmaxf(acc[1][q], acc[1][q + 1]));
-                    if (xl < T34 && pxp < Wp) o[(int64_t)pxp * C4] = fmaxf(m + bias, 0.f);
+                    if (xl < T34 && pxp < Wp) o[pxp * C4] = relu(m + bias);
                 }
             }
-            // (2) tile j + 2 from HBM into the patch A buffer conv3 read in the previous iteration, by LDS-DMA: 16-byte slot s of
-            // the buffer = (piece, pixel, position) <- chunk position ^ swizzle(pixel) of that pixel's piece (the XOR is its own
-            // inverse: the readers apply the same one); pixels outside the image come from the zero buffer
-            if (j + 2 < nloc) {
-                const int64_t tile = blockIdx.x + (j + 2) * G;
-                const int64_t win = tile / xtiles;
-                const int c0 = T34 * (int)(tile - win * xtiles);
-                unsigned char* pa = ldsA + (j & 1) * PA_BUF;
-                const uint4* img = in + win * 4 * (int64_t)Win * 8;
-                int ln = lane;
-                asm volatile("" : "+v"(ln));                  // (slot coordinates formed per tile, not held across the matrix loop)
-#pragma unroll
-                for (int m = 0; m < (PA_DMA + 3) / 4; ++m) {
-                    const int dp = cw + 4 * m;                // wave-uniform
-                    if (dp < PA_DMA) {
-                        const int sl = 64 * dp + ln;
-                        const int piece = sl >= PA_PIX * 4 ? 1 : 0, rem = sl - piece * (PA_PIX * 4);
-                        const int pixel = rem >> 2, c = (rem & 3) ^ ((pixel >> 2) & 3);
-                        const int r = pixel / PW, pc = pixel - r * PW;
-                        const int yi = r - 1, xi = c0 - 1 + pc;
-                        const uint4* src = (yi >= 0 && yi < 4 && xi >= 0 && xi < Win) ? img + (yi * Win + xi) * 8 + piece * 4 + c : zeros;
-                        if (sl < PA_CHUNKS) dma16_to_lds(src, pa + 1024 * dp);
-                    }
-                }
-            }
+            WS_STAMP(j, 4);
+            WS_STAMP(j, 5);
             // (3) conv4 of tile j, this wave's K half
             if (j >= 0 && j < nloc) {
                 const unsigned char* pbh = ldsB + (j & 1) * PB_BUF;
@@ -456,18 +589,22 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
                     acc[0][q] = 0.f;
                     acc[1][q] = 0.f;
                 }
-                conv_two_rows<128, false>(acc, wh, wl, pbh, pbh + PB_PIECE, i, 4 * kh + h);
+                PRIO_MATRIX();
+                conv_two_rows<false, 3, PB_PLANE>(acc, wh, wl, pbh, pbh + PB_PIECE, [&](int pr, int dx) { return b64_off(pr * PW + i + dx, 2 * kh + h); });
+                PRIO_VALU();
+                WS_STAMP(j, 1);
                 if (kh == 1) {
-                    uint4* xs = reinterpret_cast<uint4*>(ldsX + (j & 1) * X_BUF) + nt * (8 * 64) + lane;
+                    f32x4* xs = reinterpret_cast<f32x4*>(ldsX + (j & 1) * X_BUF) + nt * (8 * 64) + lane;
 #pragma unroll
                     for (int r4 = 0; r4 < 8; ++r4) {
                         const int mt = r4 >> 2, q = 4 * (r4 & 3);
-                        xs[r4 * 64] = make_uint4(__float_as_uint(acc[mt][q]), __float_as_uint(acc[mt][q + 1]),
-                                                 __float_as_uint(acc[mt][q + 2]), __float_as_uint(acc[mt][q + 3]));
+                        xs[r4 * 64] = f32x4{acc[mt][q], acc[mt][q + 1], acc[mt][q + 2], acc[mt][q + 3]};
                     }
                 }
             }
+            WS_STAMP(j, 2);
             __syncthreads();
+            WS_STAMP(j, 3);
         }
     }
 }
@@ -478,33 +615,88 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
 // a4 (n, 1, Wp2, 64) float32. Only for windows with four pooled rows after conv2 (f2_cnn_ws_supported).
 bool f2_cnn_ws_supported(int rows, int channels) {
     const int Hp1 = (rows - 2) / 2, Wp1 = (channels - 2) / 2;
-    return Hp1 == 4 && Wp1 >= 5;
+    // Wp1 <= 200: k_conv34_ws packs a patch column and an image offset into one register; Wp1 >= 8: the padded conv2 output
+    // (rows of 16 x tiles pixels, 128 bytes each) fits in the space f2_cnn_workspace_floats reserves for conv2's and conv3's
+    return Hp1 == 4 && Wp1 >= 8 && Wp1 <= 200;
 }
 
+#ifdef F2_WS_STAMPS
+static void ws_stamp_report(f2_ctx* ctx, const char* name, unsigned long long* d_stamps) {
+    constexpr size_t N = 8 * 8 * 32 * 8;
+    std::vector<unsigned long long> hst(N);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return;
+    if (hipMemcpy(hst.data(), d_stamps, sizeof(unsigned long long) * N, hipMemcpyDeviceToHost) != hipSuccess) return;
+    fprintf(stderr, "[ws stamps] %s: mean cycles per iteration (s_memtime), iterations 8..39 of workgroups 0..7\n", name);
+    for (int wave = 0; wave < 8; ++wave) {
+        double d[8] = {0}, iter = 0, clk = 0;
+        int cnt = 0, ccnt = 0;
+        for (int wg = 0; wg < 8; ++wg)
+            for (int it = 0; it < 32; ++it) {
+                const unsigned long long* sp = hst.data() + (((size_t)wg * 8 + wave) * 32 + it) * 8;
+                if (sp[0] == 0 || sp[3] == 0) continue;
+                for (int sl = 1; sl < 6; ++sl)
+                    if (sp[sl]) d[sl] += (double)(sp[sl] - sp[0]);
+                ++cnt;
+                if (it + 1 < 32) {
+                    const unsigned long long* sn = sp + 8;
+                    if (sn[0] && sn[7] > sp[7]) {
+                        iter += (double)(sn[0] - sp[0]);
+                        clk += (double)(sn[0] - sp[0]) / (double)(sn[7] - sp[7]) * 100e6;
+                        ++ccnt;
+                    }
+                }
+            }
+        if (!cnt) continue;
+        fprintf(stderr, "  wave %d: +matrix loop %.0f  +epilogue %.0f  +barrier %.0f  (slot4 %.0f slot5 %.0f)  iteration %.0f cycles, clock %.2f GHz\n",
+                wave, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt, d[5] / cnt, ccnt ? iter / ccnt : 0.0, ccnt ? clk / ccnt / 1e9 : 0.0);
+    }
+}
+#endif
+
 int f2_launch_cnn_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, void* a2s, float* a4) {
+#ifdef F2_WS_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    if (!d_stamps) F2_HIP(ctx, hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 8 * 8 * 32 * 8));
+    F2_HIP(ctx, hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * 8 * 8 * 32 * 8, ctx->stream));
+#define WS_STAMP_PASS , d_stamps
+#else
+#define WS_STAMP_PASS
+#endif
     const int H1 = cnn->rows, W1 = cnn->channels;
     const int Wo = W1 - 2, Wp1 = Wo / 2, Wp2 = (Wp1 - 2) / 2;
     const int grid_max = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const int Wa = 16 * (((Wo / 2) * 2 + 31) / 32);           // row pitch of the conv2 output in pixels (f2_cnn_ws_a2_floats)
     {
         const int xtiles = ((Wo / 2) * 2 + 31) / 32;
         const int64_t ntask = n * xtiles;
+        F2_CHECK(ctx, ntask < (int64_t(1) << 27), F2_ERR_UNSUPPORTED, "CNN chunk too large");
+        const tile_div xt = {(unsigned)xtiles, (unsigned)(((uint64_t(1) << 32) + xtiles - 1) / xtiles)};
         static_assert(LDS12 <= 160 * 1024, "one workgroup per CU");
         F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv12_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS12));
         const unsigned grid = (unsigned)(ntask < grid_max ? ntask : grid_max);
         hipLaunchKernelGGL(k_conv12_ws, dim3(grid), dim3(512), LDS12, ctx->stream, d_x, cnn->t(0), cnn->t(1),
                            (const bf16x8*)(cnn->blob16 + cnn->off16[0]), cnn->t(3), (__bf16*)a2s, (const float*)cnn->zeros, H1, W1,
-                           xtiles, ntask);
+                           Wa, xt, (unsigned)ntask WS_STAMP_PASS);
         F2_HIP(ctx, hipGetLastError());
+#ifdef F2_WS_STAMPS
+        ws_stamp_report(ctx, "k_conv12_ws (slot4 / slot5 = VALU phase of waves 4-7 / 0-3 done)", d_stamps);
+        F2_HIP(ctx, hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * 8 * 8 * 32 * 8, ctx->stream));
+#endif
     }
     {
         const int xtiles = (2 * Wp2 + T34 - 1) / T34;
         const int64_t ntile = n * xtiles;
+        F2_CHECK(ctx, ntile < (int64_t(1) << 27), F2_ERR_UNSUPPORTED, "CNN chunk too large");
+        const tile_div xt = {(unsigned)xtiles, (unsigned)(((uint64_t(1) << 32) + xtiles - 1) / xtiles)};
         F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv34_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS34));
         const unsigned grid = (unsigned)(ntile < grid_max ? ntile : grid_max);
         hipLaunchKernelGGL(k_conv34_ws, dim3(grid), dim3(512), LDS34, ctx->stream, (const uint4*)a2s,
                            (const bf16x8*)(cnn->blob16 + cnn->off16[1]), cnn->t(5), (const bf16x8*)(cnn->blob16 + cnn->off16[2]),
-                           cnn->t(7), a4, (const uint4*)cnn->zeros, Wp1, xtiles, ntile);
+                           cnn->t(7), a4, (const uint4*)cnn->zeros, Wp1, Wa, xt, (unsigned)ntile WS_STAMP_PASS);
         F2_HIP(ctx, hipGetLastError());
+#ifdef F2_WS_STAMPS
+        ws_stamp_report(ctx, "k_conv34_ws (waves 0-3 conv3; 4-7 conv4: slot4 = K halves combined + stored, slot5 = LDS-DMA issued)", d_stamps);
+#endif
     }
     return F2_OK;
 }

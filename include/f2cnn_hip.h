@@ -81,11 +81,15 @@ const char* f2_last_error(f2_ctx* ctx);
  *   "cnn_bf16x3"     1 (default) / 0   conv2..conv4 of f2_cnn_* / f2_eval_* on the bf16 matrix cores with both operands
  *                                      split in two bf16 pieces (three MFMAs per product, float32 accumulation: scores within
  *                                      1e-6 of the float32 matrix path, 2.2 x its speed); 0 = v_mfma_f32_32x32x2_f32 throughout
+ *   "cnn_ws"         1 (default) / 0   with "cnn_bf16x3", windows of 10 / 11 rows (the reference's 11 x C): persistent weight-
+ *                                      stationary kernels (each wave keeps the weights of its role in registers, conv1 on the
+ *                                      matrix cores too, one barrier per tile); 0 = one workgroup per tile, weights re-read
  *   "gather_blocked" 1 (default) / 0   every-sample normalised windows (f2_gather_windows without centres, f2_eval_*): logarithm
  *                                      once per envelope sample and blocks of 32 consecutive windows, bit-identical to 0 = one
  *                                      workgroup per window
- * Read-only (f2_ctx_get_option): "spectral_flagged" = utterances of the last fused call that the spectral kernel's
- * accuracy guard handed back to the two-kernel route (waits for the stream).
+ * Read-only (f2_ctx_get_option): "spectral_routed" = utterances of the last fused call that went through the spectral
+ * kernel, "spectral_flagged" = those of them its accuracy guard handed back to the two-kernel route (waits for the
+ * stream); "spectral_routed_samples" / "spectral_flagged_samples" = the same in samples.
  * Two contexts on two host threads choose independently. */
 int f2_ctx_set_option(f2_ctx* ctx, const char* key, double value);
 int f2_ctx_get_option(f2_ctx* ctx, const char* key, double* value);

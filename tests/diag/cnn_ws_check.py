@@ -13,7 +13,7 @@ from f2cnn_amd import _lib
 from f2cnn_amd.model import F2CNNModel
 
 ctx = _lib.default_context()
-m = F2CNNModel.glorot(7)
+m = F2CNNModel.glorot(7, zero_bias=False)
 rng = np.random.default_rng(11)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 14240
 x = rng.uniform(0.0, 1.0, size=(n, 11, 128)).astype(np.float32)
@@ -30,7 +30,7 @@ for name, bf, ws in (("f32", 0, 0), ("bf16x3", 1, 0), ("ws", 1, 1), ("bf16x3", 1
     cnt, ms = prof["k_cnn_forward"]
     res[name] = s
     print(f"{name}: CNN stage {ms / cnt:.3f} ms per {n} windows", flush=True)
-ref = orc.cnn_forward(x[:512], orc.glorot_weights(7))
+ref = orc.cnn_forward(x[:512], dict(m.tensors))
 for name in ("f32", "bf16x3", "ws"):
     print(f"{name} vs oracle (512 windows): max |d score| {float(np.abs(res[name][:512] - ref).max()):.3e}")
 for name in ("bf16x3", "ws"):

@@ -161,3 +161,70 @@ def test_long_rows_served_by_the_spectral_kernel_are_not_recomputed_by_the_four_
         for w, g in zip(waves, got):
             assert not np.isnan(g).any()
             assert chan_relerr(g, orc.filter_and_envelope(w, coefs, lpf, 50)) <= TOL, (case, lpf, len(w))
+
+
+def _speechlike(rng, n, kind, arg=None):
+    """Signals whose level structure is what the accuracy guard exists for (int16, full scale ~ +-30000)."""
+    noise = rng.standard_normal(n)
+    if kind == "am_steps":
+        # noise whose level steps by 40-60 dB every 50-200 ms (a talker between loud vowels and room noise)
+        gain = np.empty(n)
+        pos = 0
+        while pos < n:
+            seg = int(rng.integers(800, 3200))
+            gain[pos:pos + seg] = 10.0 ** (-rng.uniform(0.0, 3.0))            # 0 .. -60 dB
+            pos += seg
+        w = noise * gain * 9000.0
+    elif kind == "late_burst":
+        # low-level noise with a loud 5-50 ms burst that ENDS `arg` samples before the end of the utterance
+        w = noise * 9.0
+        length = int(rng.integers(80, 800))
+        stop = n - arg
+        w[stop - length:stop] += rng.standard_normal(length) * 9000.0
+    elif kind == "silence_then_speech":
+        w = np.zeros(n)
+        start = int(0.9 * n)
+        w[start:] = noise[start:] * 6000.0
+    elif kind == "zeros":
+        w = np.zeros(n)
+    elif kind == "one_sample":
+        w = np.zeros(n)
+        w[arg] = 20000.0
+    else:
+        raise ValueError(kind)
+    return np.clip(np.round(w), -32768, 32767).astype(np.int16)
+
+
+def _zero_safe_relerr(a, b):
+    scale = np.abs(b).max(axis=1)
+    err = np.abs(a - b).max(axis=1)
+    ok = scale > 0
+    assert np.all(err[~ok] == 0.0)              # an all-zero row must come out as zeros
+    return float((err[ok] / scale[ok]).max()) if ok.any() else 0.0
+
+
+@pytest.mark.parametrize("n", [16000, 30000, 50000])
+def test_accuracy_guard_on_speech_shaped_inputs(n):
+    """The guard (padding-region residual > 4e-6 of the row maximum sends the utterance back to the filterbank kernel +
+    envelope kernel) had only seen stationary noise, tones, and a single-sample click (round-3 verdict). Here: level steps of
+    40-60 dB, a loud burst ending 1 .. 2000 samples before the end, 90 % silence then speech-level noise, all zeros and a
+    single non-zero sample, in each length class of the spectral kernels. Whatever the guard decides, every channel must be
+    within 1e-5 of the oracle; the flagged fraction is reported (a guard that fired on ordinary level structure would mean the
+    headline route is not the one real data takes)."""
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    rng = np.random.default_rng(n)
+    kinds = [("am_steps", None)] * 4 + [("late_burst", d) for d in (1, 10, 100, 1000, 2000)] + \
+            [("silence_then_speech", None), ("zeros", None), ("one_sample", 0), ("one_sample", n // 2), ("one_sample", n - 300)]
+    waves = [_speechlike(rng, n, k, a) for k, a in kinds]
+    for lpf in (False, True):
+        got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
+        worst = 0.0
+        for (k, a), w, g in zip(kinds, waves, got):
+            assert not np.isnan(g).any(), (k, a)
+            e = _zero_safe_relerr(g, orc.filter_and_envelope(w, coefs, lpf, 50))
+            worst = max(worst, e)
+            assert e <= TOL, (n, lpf, k, a, e)
+        print(f"n = {n}, lpf = {lpf}: {flagged} of {len(waves)} speech-shaped utterances sent back by the guard, worst error {worst:.2e}")
+        ordinary = sum(1 for k, _ in kinds if k in ("am_steps", "silence_then_speech"))
+        assert flagged <= len(waves) - ordinary + 1      # level steps and onsets alone must not trip the guard (one tolerated)
