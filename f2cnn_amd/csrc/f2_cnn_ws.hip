@@ -7,27 +7,28 @@
 // in phases that all waves of a workgroup go through together.
 //
 // Here every wave keeps the weights of its role in registers for the whole launch (9 taps x 32 input channels x 32 outputs x 2
-// bf16 pieces = 144 VGPRs; 256 registers per wave, one 8-wave workgroup per CU, persistent over tiles) and the two waves of a
-// SIMD alternate: while one runs its matrix loop (one issue slot per 32 cycles) the other runs its VALU / LDS phase, ONE barrier
-// per tile. Measured with in-kernel stamps (tools/ws_stamps.py): a VALU phase beside a partner's matrix loop issues one
-// instruction per 8-10 cycles whatever the wave priorities, so the phases are counted in instructions - integer divisions,
-// per-store branches and per-tile address arithmetic are what a first version lost its time to.
+// bf16 pieces = 144 VGPRs; 256 registers per wave, one 8-wave workgroup per CU, persistent over tiles), with ONE barrier per
+// tile. What the other instructions cost was measured, not assumed (tools/ws_stamps.py: in-kernel stamps; tools/ubench/
+// mfma_valu_coissue.hip, mfma_fillers.hip; SQ counters under profiles/): beside a partner wave's matrix loop a wave issues only
+// ~2 VALU instructions per MFMA whatever the wave priorities, while up to ~8 per MFMA ride in the gaps of a wave's OWN matrix
+// loop for +16 % loop time - so the kernels are counted in instructions: no integer divisions, no per-store branches, per-tile
+// address arithmetic held in registers, ReLU as one v_med3, LDS-DMA for every global -> LDS copy.
 //
 //   k_conv12_ws   tile = (window, 32 conv2 columns), all 8 conv2 rows the pool keeps. Wave w: conv2 of rows 2 (w & 3), + 1 x
 //                 columns 16 (w >> 2) .. + 15 of tile t (the 32 x 32 accumulator's row index = (row, column): the 2 x 2 max-pool
-//                 stays inside the lane), and conv1 of tile t + 1 for one or two blocks of 32 patch pixels ON THE MATRIX CORES -
-//                 out^T (32 channels x 32 pixels) = W1^T (32 x 16: nine taps, the bias against a constant 1, zeros) x taps^T (16
-//                 x 32 pixels), three split-bf16 MFMAs; with the channels on the accumulator's row index a lane holds four
-//                 consecutive channels of its pixel, so ReLU + split + two 8-byte LDS stores per quad write the conv2 input
-//                 patch ([pixel][32 channels] bf16, one image per piece, 16-byte chunks XOR-swizzled) - no longer the oracle's fmaf
-//                 chain bit for bit, held to the same 2e-5 / referee rule. Waves 0-3 run conv2 first, waves 4-7 conv1 first.
-//                 The raw input of tile t + 2 arrives by LDS-DMA (no registers, zeros outside the window from a zero buffer).
-//                 Output already split in two bf16 pieces ([window][4][W/2 - 1][hi 32 | lo 32]): conv3's staging is a copy.
-//   k_conv34_ws   tile = (window, 30 conv4 columns). waves 0-3: conv3 (output tile nt, row pair: a patch row fetched from LDS
-//                 serves tap row dy of one output row and dy - 1 of the other, 48 ds_read_b128 per 108 MFMAs) of tile t + 1 from
-//                 patch A into patch B (64 channels per pixel, both pieces; accumulator rows = output channels as above);
-//                 waves 4-7: the two K halves of tile t - 1 meet (first half: sum, pool, bias, store), tile t + 2 goes from HBM
-//                 into the free patch A by LDS-DMA, then conv4 (output tile nt, K half) of tile t from patch B.
+//                 stays inside the lane). Riding behind the steps of that matrix loop: conv1 of tile t + 1 for one or two
+//                 blocks of 32 patch pixels ON THE MATRIX CORES - out^T (32 channels x 32 pixels) = W1^T (32 x 16: nine taps,
+//                 the bias against a constant 1, zeros) x taps^T (16 x 32 pixels), three split-bf16 MFMAs; with the channels on
+//                 the accumulator's row index a lane holds four consecutive channels of its pixel, so ReLU + split + two 8-byte
+//                 LDS stores per quad write the conv2 input patch - no longer the oracle's fmaf chain bit for bit, held to the
+//                 same 2e-5 / referee rule; the LDS-DMA of the raw input of tile t + 2 (zeros outside the window from a zero
+//                 buffer); bias + ReLU + split + stores of the pooled outputs of tile t - 1. Output already split in two bf16
+//                 pieces ([window][4][16 x tiles][hi 32 | lo 32]): conv3's staging is a copy.
+//   k_conv34_ws   tile = (window, 30 conv4 columns). waves 0-3: LDS-DMA of tile t + 2 from HBM into the free patch A, conv3 (output
+//                 tile nt, row pair: a patch row fetched from LDS serves tap row dy of one output row and dy - 1 of the other,
+//                 48 ds_read_b128 per 108 MFMAs) of tile t + 1 from patch A into patch B (64 channels per pixel, both pieces;
+//                 accumulator rows = output channels as above); waves 4-7: the two K halves of tile t - 1 meet (first half: sum,
+//                 pool, bias, store), then conv4 (output tile nt, K half) of tile t from patch B.
 //
 // Layout of an MFMA operand (tools/ubench/mfma_bf16_layout.hip): lane (i, h) supplies k = 8 h .. 8 h + 7 of row / column i;
 // accumulator register q of lane (i, h) is row (q & 3) + 8 (q >> 2) + 4 h, column i.
@@ -155,9 +156,12 @@ __device__ __forceinline__ void conv_two_rows(f32x16 (&acc)[2], const bf16x8 (&w
 
 // One 32 x 32 accumulator of the same convolution: off(dy, dx) = byte offset in plane 0 of this lane's pixel for tap (dy, dx);
 // 18 steps, two ds_read_b128 + three MFMAs each, DEPTH - 1 steps requested ahead.
-template <int DEPTH, int PLANE, class OFF>
+// fill(f) is placed behind the MFMAs of step f: other work of the SAME wave rides in the gaps of its own matrix loop (up to ~8
+// VALU instructions per MFMA for +16 % loop time, tools/ubench/mfma_fillers.hip; a partner wave's VALU beside the loop gets ~2 per
+// MFMA, tools/ubench/mfma_valu_coissue.hip).
+template <int DEPTH, int PLANE, class OFF, class FILL>
 __device__ __forceinline__ void conv_one_tile(f32x16& acc, const bf16x8 (&wh)[18], const bf16x8 (&wl)[18],
-                                              const unsigned char* ph, const unsigned char* pl, OFF off) {
+                                              const unsigned char* ph, const unsigned char* pl, OFF off, FILL fill) {
     constexpr int NF = 18;
     bf16x8 fh[DEPTH], fl[DEPTH];
     auto fetch = [&](int f, int slot) {
@@ -176,6 +180,7 @@ __device__ __forceinline__ void conv_one_tile(f32x16& acc, const bf16x8 (&wh)[18
         acc = MFMA16(fl[s], wh[f], acc);
         acc = MFMA16(fh[s], wl[f], acc);
         acc = MFMA16(fh[s], wh[f], acc);
+        fill(f);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -216,11 +221,10 @@ __device__ __forceinline__ void dma16_to_lds(const void* g, unsigned lds_addr) {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Per iteration k of a workgroup (its tasks t_0, t_1, ...; ONE barrier per iteration), every wave:
-//   conv2 + pool of its 2 x 16 pixels of t_k from patch buffer k & 1                                   (matrix loop)
-//   conv1 of its one or two pixel blocks of t_(k+1), from the raw input that landed an iteration ago, into patch buffer
-//   (k + 1) & 1; its pieces of the raw input of t_(k+2): HBM -> LDS by LDS-DMA                         (VALU / LDS phase)
-// waves 0-3 in this order, waves 4-7 (their partners on the SIMDs) the other way round.
+// Per iteration k of a workgroup (its tasks t_0, t_1, ...; ONE barrier per iteration), every wave: the matrix loop of conv2 of
+// its 2 x 16 pixels of t_k from patch buffer k & 1 and, behind its steps: its LDS-DMA pieces of the raw input of t_(k+2), conv1
+// of its one or two pixel blocks of t_(k+1) (from the raw input that landed an iteration ago, into patch buffer (k + 1) & 1), the
+// stores of its pooled outputs of t_(k-1). The first two and the last two iterations run the same pieces one after the other.
 __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, const float* __restrict__ w1,
                                                    const float* __restrict__ b1, const bf16x8* __restrict__ w2s,
                                                    const float* __restrict__ b2, __bf16* __restrict__ out,
@@ -288,105 +292,138 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
     const int dma0 = wave >= 3 ? wave - 3 : -1, dma1 = (wave == 3 || wave == 4) ? wave + 2 : -1;
     __syncthreads();
 
-    auto vphase = [&](int k) {
-        if (k + 2 < nloc && dma0 >= 0) {
-            // raw input region of task t_(k+2): element e = (row r, column c) of the 12 x 36 region, one dword per lane
-            unsigned win, xi0;
-            tile_split(blockIdx.x + (unsigned)(k + 2) * G, xt, win, xi0);
-            const int x0 = 32 * (int)xi0;
-            const float* img = x + (size_t)win * (size_t)(Hin * Win);
-            const unsigned xb = __builtin_amdgcn_readfirstlane(lds_address(lds) + (k & 1) * XIN_STRIDE);
+    // ---- the VALU / LDS work of an iteration, in pieces that ride in the gaps of the matrix loop ----
+    // LDS-DMA piece m (0, 1) of the raw input of task t_(k+2): element e = (row r, column c) of the 12 x 36 region, a dword per lane
+    auto dma_piece = [&](int k, int m) {
+        const int piece = m == 0 ? dma0 : dma1;
+        if (piece < 0) return;                                 // wave-uniform
+        unsigned win, xi0;
+        tile_split(blockIdx.x + (unsigned)(k + 2) * G, xt, win, xi0);
+        const int x0 = 32 * (int)xi0;
+        const float* img = x + (size_t)win * (size_t)(Hin * Win);
+        const unsigned xb = __builtin_amdgcn_readfirstlane(lds_address(lds) + (k & 1) * XIN_STRIDE + 256 * piece);
+        const int e = 64 * piece + lane;
+        const int r = e / XW, c = e - r * XW;
+        const int yi = r - 1, xi = x0 - 1 + c;
+        const float* src = ((unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win) ? img + yi * Win + xi : zeros;
+        if (e < XIN) dma4_to_lds(src, xb);
+    };
+    // conv1 of pixel block tt of task t_(k+1), stage c: 0 taps from LDS, 1 split, 2 the three MFMAs, 3 .. 6 ReLU + split + store of
+    // channels 8 g + 4 h .. + 3 (g = c - 3)
+    float xv[8];
+    bf16x8 xh, xl;
+    f32x16 a1;
+    auto conv1_stage = [&](int k, int tt, int c) {
+        const unsigned char* xin = lds + ((k + 1) & 1) * XIN_STRIDE;
+        unsigned char* ph = ldsP + ((k + 1) & 1) * P12_BUF;
+        if (c == 0) {
+            const float* x0p = reinterpret_cast<const float*>(xin + xoff0[tt]);
+            const float* x1p = reinterpret_cast<const float*>(xin + xoff1[tt]);
+            xv[0] = x0p[0];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int piece = m == 0 ? dma0 : dma1;
-                if (piece >= 0) {
-                    const int e = 64 * piece + lane;
-                    const int r = e / XW, c = e - r * XW;
-                    const int yi = r - 1, xi = x0 - 1 + c;
-                    const float* src = ((unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win) ? img + yi * Win + xi : zeros;
-                    if (e < XIN) dma4_to_lds(src, __builtin_amdgcn_readfirstlane(xb + 256 * piece));
-                }
+            for (int j = 1; j < 8; ++j) xv[j] = x1p[(j / 3) * XW + (j % 3)];
+        } else if (c == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 vh = (__bf16)xv[j];
+                xh[j] = vh;
+                xl[j] = (__bf16)(xv[j] - (float)vh);
             }
+        } else if (c == 2) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a1[q] = 0.f;
+            a1 = MFMA16(w1l, xh, a1);
+            a1 = MFMA16(w1h, xl, a1);
+            a1 = MFMA16(w1h, xh, a1);
+        } else if (poff[tt] >= 0) {
+            const int g = c - 3;
+            bf16x4 vh, vl;
+            split4(relu(a1[4 * g]), relu(a1[4 * g + 1]), relu(a1[4 * g + 2]), relu(a1[4 * g + 3]), vh, vl);
+            const int off = (g >> 1) * P12_PLANE + (poff[tt] ^ ((g & 1) << 4));
+            *reinterpret_cast<bf16x4*>(ph + off) = vh;
+            *reinterpret_cast<bf16x4*>(ph + P12_PIECE + off) = vl;
         }
-        if (k + 1 >= 0 && k + 1 < nloc) {
-            const unsigned char* xin = lds + ((k + 1) & 1) * XIN_STRIDE;
-            unsigned char* ph = ldsP + ((k + 1) & 1) * P12_BUF;
+    };
+    // conv2 + pool of this wave's 2 x 16 pixels of task t_k, `fill` riding in the matrix loop. The four pooled maxima stay in
+    // registers (pm): bias, ReLU, split and the stores are deferred to store_pooled(), which rides in the NEXT matrix loop.
+    float pm[4];
+    auto conv2 = [&](int k, auto fill) {
+        const unsigned char* ph = ldsP + (k & 1) * P12_BUF;
+        f32x16 acc;
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                if (tt >= nblk) continue;                      // wave-uniform
-                const float* x0p = reinterpret_cast<const float*>(xin + xoff0[tt]);
-                const float* x1p = reinterpret_cast<const float*>(xin + xoff1[tt]);
-                float xv[8];
-                xv[0] = x0p[0];
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        conv_one_tile<3, P12_PLANE>(acc, wh, wl, ph, ph + P12_PIECE, [&](int dy, int dx) { return c32_off(row2 + dy, col2 + dx, h); }, fill);
+        WS_STAMP(k, 1);
+        // 2 x 2 pool inside the lane: registers q, q + 1 = columns 2 t, 2 t + 1 of the first row, q + 8, q + 9 of the second
 #pragma unroll
-                for (int j = 1; j < 8; ++j) xv[j] = x1p[(j / 3) * XW + (j % 3)];
-                bf16x8 xh, xl;
+        for (int kk = 0; kk < 4; ++kk) pm[kk] = fmaxf(fmaxf(acc[2 * kk], acc[2 * kk + 1]), fmaxf(acc[2 * kk + 8], acc[2 * kk + 9]));
+    };
+    // outputs kk0, kk0 + 1 of task t_k. The output rows have a pitch of Wa = 16 x tiles pixels, so every lane's four pixels exist
+    // (columns past the image land in the padding, which conv3's loader never reads): no bounds tests, one address, immediate offsets.
+    auto store_pooled = [&](int k, int kk0) {
+        unsigned win, xi0;
+        tile_split(blockIdx.x + (unsigned)k * G, xt, win, xi0);
+        const int x0 = 32 * (int)xi0 + 16 * ch;
+        __bf16* o = out + ((size_t)(win * 4 + rp) * (size_t)Wa + (size_t)((x0 >> 1) + 2 * h)) * 64 + i;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const __bf16 vh = (__bf16)xv[j];
-                    xh[j] = vh;
-                    xl[j] = (__bf16)(xv[j] - (float)vh);
-                }
-                f32x16 a;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = 0.f;
-                a = MFMA16(w1l, xh, a);
-                a = MFMA16(w1h, xl, a);
-                a = MFMA16(w1h, xh, a);
-                if (poff[tt] >= 0) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {              // channels 8 g + 4 h .. + 3 of the pixel
-                        bf16x4 vh, vl;
-                        split4(relu(a[4 * g]), relu(a[4 * g + 1]), relu(a[4 * g + 2]), relu(a[4 * g + 3]), vh, vl);
-                        const int off = (g >> 1) * P12_PLANE + (poff[tt] ^ ((g & 1) << 4));
-                        *reinterpret_cast<bf16x4*>(ph + off) = vh;
-                        *reinterpret_cast<bf16x4*>(ph + P12_PIECE + off) = vl;
-                    }
-                }
-            }
+        for (int kk = kk0; kk < kk0 + 2; ++kk) {
+            const int q = 2 * kk;
+            const int dpx = ((q & 3) + 8 * (q >> 2)) >> 1;                     // 0, 1, 4, 5
+            const float v = relu(pm[kk] + bias);
+            const __bf16 vh = (__bf16)v;
+            const __bf16 vl = (__bf16)(v - (float)vh);
+            o[dpx * 64] = vh;
+            o[dpx * 64 + 32] = vl;
         }
     };
 
+    bool pending = false;                                      // pm holds the maxima of task t_(k-1), not stored yet
     for (int k = -2; k < nloc; ++k) {
         WS_STAMP(k, 0);
-        if (wave >= 4) vphase(k);
-        WS_STAMP(k, 4);
-        if (k >= 0) {
-            unsigned win, xi0;
-            tile_split(blockIdx.x + (unsigned)k * G, xt, win, xi0);
-            const int x0 = 32 * (int)xi0 + 16 * ch;
-            const unsigned char* ph = ldsP + (k & 1) * P12_BUF;
-            f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-            PRIO_MATRIX();
-            conv_one_tile<4, P12_PLANE>(acc, wh, wl, ph, ph + P12_PIECE, [&](int dy, int dx) { return c32_off(row2 + dy, col2 + dx, h); });
-            PRIO_VALU();
-            if (wave >= 4) dma_wait();                        // (its LDS-DMA of this iteration, issued a matrix loop ago; before the stores)
-            WS_STAMP(k, 1);
-            // 2 x 2 pool inside the lane: registers q, q + 1 = columns 2 t, 2 t + 1 of the first row, q + 8, q + 9 of the second.
-            // The output rows have a pitch of Wa = 16 x tiles pixels, so every lane's four pixels exist (columns past the image
-            // land in the padding, which conv3's loader never reads): no bounds tests, one address, immediate offsets.
-            __bf16* o = out + ((size_t)(win * 4 + rp) * (size_t)Wa + (size_t)((x0 >> 1) + 2 * h)) * 64 + i;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int q = 2 * kk;
-                const int dpx = ((q & 3) + 8 * (q >> 2)) >> 1;                     // 0, 1, 4, 5
-                const float m = fmaxf(fmaxf(acc[q], acc[q + 1]), fmaxf(acc[q + 8], acc[q + 9]));
-                const float v = relu(m + bias);
-                const __bf16 vh = (__bf16)v;
-                const __bf16 vl = (__bf16)(v - (float)vh);
-                o[dpx * 64] = vh;
-                o[dpx * 64 + 32] = vl;
+        if (k >= 0 && k + 2 < nloc) {
+            // steady state: the LDS-DMA pieces (first: they have the whole loop to land), the conv1 stages and the stores of the
+            // previous task sit behind the steps of the matrix loop
+            if (nblk == 2) {
+                conv2(k, [&](int f) {
+                    if (f < 7) conv1_stage(k, 0, f);
+                    else if (f < 14) conv1_stage(k, 1, f - 7);
+                    else if (f < 16 && pending) store_pooled(k - 1, 2 * (f - 14));
+                });
+            } else {
+                conv2(k, [&](int f) {
+                    if (f < 2) dma_piece(k, f);
+                    else if (f < 16 && (f & 1) == 0) conv1_stage(k, 0, (f - 2) >> 1);
+                    else if ((f == 15 || f == 17) && pending) store_pooled(k - 1, f - 15);
+                });
             }
+        } else {
+            // first and last iterations: what there is, one thing after the other
+            if (pending) {
+                store_pooled(k - 1, 0);
+                store_pooled(k - 1, 2);
+            }
+            if (k + 2 < nloc) {
+                dma_piece(k, 0);
+                dma_piece(k, 1);
+            }
+            if (k + 1 >= 0 && k + 1 < nloc) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    if (tt < nblk) {
+#pragma unroll
+                        for (int c = 0; c < 7; ++c) conv1_stage(k, tt, c);
+                    }
+            }
+            WS_STAMP(k, 4);
+            if (k >= 0) conv2(k, [](int) {});
+        }
+        pending = k >= 0;
+        if (k == nloc - 1 && pending) {
+            store_pooled(k, 0);
+            store_pooled(k, 2);
         }
         WS_STAMP(k, 2);
-        if (wave < 4) {
-            vphase(k);
-            dma_wait();
-        } else if (k < 0) {
-            dma_wait();                                       // (the first two iterations have no matrix loop to wait behind)
-        }
+        dma_wait();
         WS_STAMP(k, 5);
         __syncthreads();
         WS_STAMP(k, 3);
