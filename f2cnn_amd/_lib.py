@@ -45,6 +45,7 @@ SIGNATURES = {
     "f2_event_destroy": (_i, [_vp, _vp]),
     "f2_event_record": (_i, [_vp, _vp]),
     "f2_event_elapsed_ms": (_i, [_vp, _vp, _vp, _P(C.c_float)]),
+    "f2_event_query": (_i, [_vp, _vp, _P(C.c_int)]),
     "f2_prof_enable": (_i, [_vp, _i]),
     "f2_prof_reset": (_i, [_vp]),
     "f2_prof_get": (_i, [_vp, _i, _P(_i), _P(C.c_float)]),
@@ -237,6 +238,12 @@ class Context:
         ms = C.c_float()
         self.check(self.lib.f2_event_elapsed_ms(self.handle, e0, e1, C.byref(ms)))
         return ms.value
+
+    def event_done(self, ev):
+        """True once the stream has passed the event (does not wait)."""
+        done = C.c_int()
+        self.check(self.lib.f2_event_query(self.handle, ev, C.byref(done)))
+        return bool(done.value)
 
     def destroy_event(self, ev):
         self.check(self.lib.f2_event_destroy(self.handle, ev))

@@ -32,6 +32,63 @@ int f2_reserve(f2_ctx* ctx, f2_scratch& s, size_t bytes) {
     return F2_OK;
 }
 
+int f2_upload_async(f2_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    if (bytes == 0) return F2_OK;
+    constexpr size_t RING = size_t(8) << 20, ALIGN = 256;
+    // finished one-off buffers of earlier large uploads
+    for (size_t i = 0; i < ctx->up_big.size();) {
+        if (hipEventQuery(ctx->up_big[i].second) == hipSuccess) {
+            (void)hipHostFree(ctx->up_big[i].first);
+            ctx->prof_pool.push_back(ctx->up_big[i].second);
+            ctx->up_big.erase(ctx->up_big.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+    hipEvent_t ev;
+    if (!ctx->prof_pool.empty()) {
+        ev = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+    } else {
+        F2_HIP(ctx, hipEventCreate(&ev));
+    }
+    if (bytes > RING / 4) {
+        void* h = nullptr;
+        hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return f2_fail(ctx, F2_ERR_NOMEM, "hipHostMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
+        memcpy(h, src, bytes);
+        F2_HIP(ctx, hipMemcpyAsync(d_dst, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        F2_HIP(ctx, hipEventRecord(ev, ctx->stream));
+        ctx->up_big.push_back({h, ev});
+        return F2_OK;
+    }
+    if (!ctx->up_ring) {
+        F2_HIP(ctx, hipHostMalloc((void**)&ctx->up_ring, RING, hipHostMallocDefault));
+        ctx->up_cap = RING;
+    }
+    const size_t need = (bytes + ALIGN - 1) & ~(ALIGN - 1);
+    size_t begin = ctx->up_head;
+    if (begin + need > ctx->up_cap) begin = 0;
+    // the ring region [begin, begin + need) must not be the source of a copy that is still pending (oldest spans first;
+    // normally long done: the ring holds thousands of the small arrays a call uploads)
+    while (!ctx->up_inflight.empty()) {
+        const f2_ctx::up_span& sp = ctx->up_inflight.front();
+        const bool overlaps = sp.begin < begin + need && begin < sp.end;
+        if (!overlaps && hipEventQuery(sp.done) != hipSuccess) break;
+        if (overlaps) F2_HIP(ctx, hipEventSynchronize(sp.done));
+        ctx->prof_pool.push_back(sp.done);
+        ctx->up_inflight.erase(ctx->up_inflight.begin());
+    }
+    for (const f2_ctx::up_span& sp : ctx->up_inflight)
+        if (sp.begin < begin + need && begin < sp.end) F2_HIP(ctx, hipEventSynchronize(sp.done));
+    memcpy(ctx->up_ring + begin, src, bytes);
+    F2_HIP(ctx, hipMemcpyAsync(d_dst, ctx->up_ring + begin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    F2_HIP(ctx, hipEventRecord(ev, ctx->stream));
+    ctx->up_inflight.push_back({begin, begin + need, ev});
+    ctx->up_head = begin + need;
+    return F2_OK;
+}
+
 static int prof_event(f2_ctx* ctx, hipEvent_t* ev) {
     if (!ctx->prof_pool.empty()) {
         *ev = ctx->prof_pool.back();
@@ -67,7 +124,7 @@ int f2_prof_end(f2_ctx* ctx, int kernel_id) {
 
 extern "C" {
 
-int f2_version(void) { return 103; }   // 101: f2_eval_batch; 102: f2_host_alloc, F2_MEM_HOST_ASYNC; 103: f2_ctx_set_option
+int f2_version(void) { return 104; }   // 101: f2_eval_batch; 102: f2_host_alloc, F2_MEM_HOST_ASYNC; 103: f2_ctx_set_option; 104: f2_event_query
 
 int f2_device_count(int* count) {
     if (!count) return f2_fail(nullptr, F2_ERR_INVALID, "count is NULL");
@@ -165,6 +222,12 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     for (auto& prec : ctx->tw_sp)
         for (f2_scratch& sc : prec)
             if (sc.ptr) (void)hipFree(sc.ptr);
+    for (auto& sp : ctx->up_inflight) (void)hipEventDestroy(sp.done);
+    for (auto& b : ctx->up_big) {
+        (void)hipHostFree(b.first);
+        (void)hipEventDestroy(b.second);
+    }
+    if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -374,6 +437,15 @@ int f2_event_elapsed_ms(f2_ctx* ctx, void* start, void* stop, float* ms) {
     return F2_OK;
 }
 
+int f2_event_query(f2_ctx* ctx, void* event, int* done) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, event && done, F2_ERR_INVALID, "null argument");
+    const hipError_t e = hipEventQuery((hipEvent_t)event);
+    if (e != hipSuccess && e != hipErrorNotReady) return f2_fail(ctx, F2_ERR_HIP, "hipEventQuery -> %s", hipGetErrorString(e));
+    *done = e == hipSuccess ? 1 : 0;
+    return F2_OK;
+}
+
 int f2_prof_enable(f2_ctx* ctx, int on) {
     F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
     ctx->prof_on = on != 0;
@@ -439,10 +511,8 @@ int f2_upload_offsets(f2_ctx* ctx, const int64_t* offsets, int B) {
         return F2_OK;  // same batch shape as the previous call: the device copy is still valid
     ctx->offsets_host.clear();
     F2_TRY(f2_reserve(ctx, ctx->offsets, sizeof(int64_t) * (size_t)(B + 1)));
-    F2_HIP(ctx, hipMemcpyAsync(ctx->offsets.ptr, offsets, sizeof(int64_t) * (size_t)(B + 1), hipMemcpyHostToDevice,
-                               ctx->stream));
-    // the host array belongs to the caller: do not return before the copy has read it
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (the host array belongs to the caller: staged through page-locked memory, the call does not wait for the copy)
+    F2_TRY(f2_upload_async(ctx, ctx->offsets.ptr, offsets, sizeof(int64_t) * (size_t)(B + 1)));
     ctx->offsets_host.assign(offsets, offsets + B + 1);
     return F2_OK;
 }
@@ -453,8 +523,7 @@ int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C) {
         return F2_OK;
     ctx->coefs_host.clear();
     F2_TRY(f2_reserve(ctx, ctx->coefs, sizeof(double) * 10 * (size_t)C));
-    F2_HIP(ctx, hipMemcpyAsync(ctx->coefs.ptr, coefs, sizeof(double) * 10 * (size_t)C, hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    F2_TRY(f2_upload_async(ctx, ctx->coefs.ptr, coefs, sizeof(double) * 10 * (size_t)C));
     ctx->coefs_host.assign(coefs, coefs + (size_t)C * 10);
     ctx->spec_coefs_ok = -1;      // eligibility of this table for the spectral kernel: decided on first use
     return F2_OK;
@@ -484,8 +553,7 @@ int f2_plan_handoff(f2_ctx* ctx, const int64_t* h_offsets, int B, int C, int pre
     if (!any_long) return F2_OK;
     F2_TRY(f2_reserve(ctx, ctx->handoff, sizeof(float) * (size_t)floats));
     F2_TRY(f2_reserve(ctx, ctx->handoff_off, sizeof(int64_t) * (size_t)B));
-    F2_HIP(ctx, hipMemcpyAsync(ctx->handoff_off.ptr, off.data(), sizeof(int64_t) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `off` is a local
+    F2_TRY(f2_upload_async(ctx, ctx->handoff_off.ptr, off.data(), sizeof(int64_t) * (size_t)B));
     ctx->handoff_off_host = off;
     plan->d_x32 = (float*)ctx->handoff.ptr;
     plan->d_x32_off = (const int64_t*)ctx->handoff_off.ptr;
@@ -619,13 +687,11 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
                 pos[l] = meta.size();
                 meta.insert(meta.end(), lists[l].begin(), lists[l].end());
             }
-            if (meta != ctx->spec_meta_host) {   // new batch shape (as f2_upload_offsets: the upload waits for the stream)
+            if (meta != ctx->spec_meta_host) {   // new batch shape (as f2_upload_offsets: staged, not waited for)
                 ctx->spec_meta_host.clear();
                 F2_TRY(f2_reserve(ctx, ctx->spec_meta, sizeof(int) * meta.size()));
                 F2_TRY(f2_reserve(ctx, ctx->spec_uflag, sizeof(int) * (size_t)B));
-                F2_HIP(ctx, hipMemcpyAsync(ctx->spec_meta.ptr, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice,
-                                           ctx->stream));
-                F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                F2_TRY(f2_upload_async(ctx, ctx->spec_meta.ptr, meta.data(), sizeof(int) * meta.size()));
                 ctx->spec_meta_host = meta;
             }
             int* uflag = (int*)ctx->spec_uflag.ptr;

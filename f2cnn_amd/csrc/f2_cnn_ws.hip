@@ -108,9 +108,10 @@ __device__ __forceinline__ void tile_split(unsigned t, tile_div td, unsigned& q,
 // dy = pr of output row 0 and dy = pr - 1 of output row 1. off(pr, dx) = byte offset of this lane's 16 bytes in plane 0 for patch
 // row pr, tap column dx; PLANE = bytes between the two 16-channel planes. SWAP: the weights are the A operand (accumulator rows =
 // output channels, columns = pixels), otherwise the B operand (rows = pixels, columns = output channels).
-template <bool SWAP, int DEPTH, int PLANE, class OFF>
+// fill(f) rides behind the MFMAs of fragment f (see conv_one_tile); output row 0 is complete once fragment 17 is done.
+template <bool SWAP, int DEPTH, int PLANE, class OFF, class FILL>
 __device__ __forceinline__ void conv_two_rows(f32x16 (&acc)[2], const bf16x8 (&wh)[18], const bf16x8 (&wl)[18],
-                                              const unsigned char* ph, const unsigned char* pl, OFF off) {
+                                              const unsigned char* ph, const unsigned char* pl, OFF off, FILL fill) {
     constexpr int NF = 24;
     bf16x8 fh[DEPTH], fl[DEPTH];
     auto fetch = [&](int f, int slot) {
@@ -150,6 +151,7 @@ __device__ __forceinline__ void conv_two_rows(f32x16 (&acc)[2], const bf16x8 (&w
                 acc[1] = MFMA16(fh[s], wh[st], acc[1]);
             }
         }
+        fill(f);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -508,23 +510,19 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
         }
         for (int j = -2; j <= nloc; ++j) {
             WS_STAMP(j, 0);
-            // tile j + 2 from HBM into the patch A buffer this wave's matrix loop read in the PREVIOUS iteration, by LDS-DMA (this
-            // iteration's loop read the other one); pixels outside the image come from the zero buffer
-            if (j + 2 < nloc) {
+            // LDS-DMA piece m of tile j + 2: HBM -> the patch A buffer this wave's matrix loop read in the PREVIOUS iteration (this
+            // iteration's loop reads the other one); pixels outside the image come from the zero buffer
+            auto dma_piece = [&](int m) {
+                const int dp = wave + 4 * m;                  // wave-uniform
+                if (dp >= PA_DMA || j + 2 >= nloc) return;
                 unsigned win, xi0;
                 tile_split(blockIdx.x + (unsigned)(j + 2) * G, xt, win, xi0);
-                const int cm1 = T34 * (int)xi0 - 1;                   // image column of patch column 0
-                const unsigned pa = __builtin_amdgcn_readfirstlane(lds_address(ldsA) + (j & 1) * PA_BUF);
+                const int cm1 = T34 * (int)xi0 - 1;           // image column of patch column 0
+                const unsigned pa = __builtin_amdgcn_readfirstlane(lds_address(ldsA) + (j & 1) * PA_BUF + 1024 * dp);
                 const uint4* img = in + ((size_t)win * 4 * (size_t)Wa + cm1) * 8;
-#pragma unroll
-                for (int m = 0; m < PA_DMA_PER_WAVE; ++m) {
-                    const int dp = wave + 4 * m;                // wave-uniform
-                    if (dp < PA_DMA) {
-                        const uint4* src = (unsigned)(cm1 + (int)(relpc[m] >> 24)) < (unsigned)Win ? img + (relpc[m] & 0xFFFFFFu) : zeros;
-                        if (dp < PA_DMA - 1 || lane < PA_CHUNKS - 64 * (PA_DMA - 1)) dma16_to_lds(src, __builtin_amdgcn_readfirstlane(pa + 1024 * dp));
-                    }
-                }
-            }
+                const uint4* src = (unsigned)(cm1 + (int)(relpc[m] >> 24)) < (unsigned)Win ? img + (relpc[m] & 0xFFFFFFu) : zeros;
+                if (dp < PA_DMA - 1 || lane < PA_CHUNKS - 64 * (PA_DMA - 1)) dma16_to_lds(src, pa);
+            };
             const int jt = j + 1;                             // conv3 works one tile ahead of conv4
             if (jt >= 0 && jt < nloc) {
                 const unsigned char* pa = ldsA + (jt & 1) * PA_BUF;
@@ -540,23 +538,31 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
                         acc[1][4 * g + r] = bq[r];
                     }
                 }
+                // ReLU + split + store of channels 32 nt + 8 g + 4 h .. + 3 of output row mt
+                auto epilogue = [&](int mt, int g) {
+                    const int pb = (2 * rp + mt) * PW + i;
+                    const int base = b64_off(pb, 2 * nt) + 8 * h;   // chunk 2 nt + (g & 1) of plane g >> 1: base ^ ((g & 1) << 4)
+                    bf16x4 vh, vl;
+                    split4(relu(acc[mt][4 * g]), relu(acc[mt][4 * g + 1]), relu(acc[mt][4 * g + 2]), relu(acc[mt][4 * g + 3]), vh, vl);
+                    const int off = (g >> 1) * PB_PLANE + (base ^ ((g & 1) << 4));
+                    *reinterpret_cast<bf16x4*>(pbh + off) = vh;
+                    *reinterpret_cast<bf16x4*>(pbh + PB_PIECE + off) = vl;
+                };
                 PRIO_MATRIX();
-                conv_two_rows<true, 3, PA_PLANE>(acc, wh, wl, pa, pa + PA_PIECE, [&](int pr, int dx) { return a32_off((2 * rp + pr) * PW + i + dx, h); });
+                // behind the fragments of the matrix loop: the LDS-DMA pieces (first: they have the whole iteration to land) and,
+                // once output row 0 is complete (fragment 17), its epilogue
+                conv_two_rows<true, 3, PA_PLANE>(acc, wh, wl, pa, pa + PA_PIECE, [&](int pr, int dx) { return a32_off((2 * rp + pr) * PW + i + dx, h); },
+                                                 [&](int f) {
+                                                     if (f < PA_DMA_PER_WAVE) dma_piece(f);
+                                                     else if (f >= 19 && f < 23) epilogue(0, f - 19);
+                                                 });
                 PRIO_VALU();
                 WS_STAMP(j, 1);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int pb = (2 * rp + mt) * PW + i;
-                    const int base = b64_off(pb, 2 * nt) + 8 * h;   // chunk 2 nt + (g & 1) of plane g >> 1: base ^ ((g & 1) << 4)
+                for (int g = 0; g < 4; ++g) epilogue(1, g);
+            } else {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {             // channels 32 nt + 8 g + 4 h .. + 3 of pixel pb
-                        bf16x4 vh, vl;
-                        split4(relu(acc[mt][4 * g]), relu(acc[mt][4 * g + 1]), relu(acc[mt][4 * g + 2]), relu(acc[mt][4 * g + 3]), vh, vl);
-                        const int off = (g >> 1) * PB_PLANE + (base ^ ((g & 1) << 4));
-                        *reinterpret_cast<bf16x4*>(pbh + off) = vh;
-                        *reinterpret_cast<bf16x4*>(pbh + PB_PIECE + off) = vl;
-                    }
-                }
+                for (int m = 0; m < PA_DMA_PER_WAVE; ++m) dma_piece(m);
             }
             dma_wait();                                       // (issued a matrix loop and an epilogue ago)
             WS_STAMP(j, 2);
@@ -592,23 +598,24 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
         }
         for (int j = -2; j <= nloc; ++j) {
             WS_STAMP(j, 0);
-            // (1) first K half: the partial sums the second half left in LDS an iteration ago complete tile j - 1
-            if (kh == 0 && j - 1 >= 0 && j - 1 < nloc) {
+            // (1) the two K halves of tile j - 1 meet: each wave kept the accumulator registers of four of the eight pooled
+            // outputs of a lane (first half: q = 0 .. 7, second half: q = 8 .. 15) and reads its partner's partial sums of those
+            // from LDS; sum, pool, bias, ReLU, store
+            if (j - 1 >= 0 && j - 1 < nloc) {
                 unsigned win, xi0;
                 tile_split(blockIdx.x + (unsigned)(j - 1) * G, xt, win, xi0);
                 const int c0 = T34 * (int)xi0;
-                const f32x4* xs = reinterpret_cast<const f32x4*>(ldsX + ((j - 1) & 1) * X_BUF) + nt * (8 * 64) + lane;
-#pragma unroll
-                for (int r4 = 0; r4 < 8; ++r4) {
-                    const f32x4 v = xs[r4 * 64];
-                    const int mt = r4 >> 2, q = 4 * (r4 & 3);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[mt][q + r] += v[r];
-                    if ((r4 & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // (two reads in flight, not eight: registers)
-                }
+                const f32x4* xs = reinterpret_cast<const f32x4*>(ldsX + ((j - 1) & 1) * X_BUF) + ((nt * 2 + (kh ^ 1)) * 4) * 64 + lane;
                 float* o = out + (size_t)win * (size_t)(Wp * C4) + nt * 32 + i;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int r4 = 0; r4 < 4; ++r4) {              // quad (mt, half): registers 8 kh + 4 (r4 & 1) .. + 3 of row mt = r4 >> 1
+                    const f32x4 v = xs[r4 * 64];
+                    const int mt = r4 >> 1, q = 8 * kh + 4 * (r4 & 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][q + r] += v[r];
+                }
+#pragma unroll
+                for (int k = 4 * kh; k < 4 * kh + 4; ++k) {
                     const int q = 2 * k;
                     const int xl = (q & 3) + 8 * (q >> 2) + 4 * h;    // even conv4 column inside the tile
                     const int pxp = (c0 + xl) >> 1;
@@ -627,16 +634,16 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
                     acc[1][q] = 0.f;
                 }
                 PRIO_MATRIX();
-                conv_two_rows<false, 3, PB_PLANE>(acc, wh, wl, pbh, pbh + PB_PIECE, [&](int pr, int dx) { return b64_off(pr * PW + i + dx, 2 * kh + h); });
+                conv_two_rows<false, 3, PB_PLANE>(acc, wh, wl, pbh, pbh + PB_PIECE, [&](int pr, int dx) { return b64_off(pr * PW + i + dx, 2 * kh + h); },
+                                                  [](int) {});
                 PRIO_VALU();
                 WS_STAMP(j, 1);
-                if (kh == 1) {
-                    f32x4* xs = reinterpret_cast<f32x4*>(ldsX + (j & 1) * X_BUF) + nt * (8 * 64) + lane;
+                // the registers the OTHER K half finishes: q = 8 (1 - kh) .. + 7 of both rows
+                f32x4* xs = reinterpret_cast<f32x4*>(ldsX + (j & 1) * X_BUF) + ((nt * 2 + kh) * 4) * 64 + lane;
 #pragma unroll
-                    for (int r4 = 0; r4 < 8; ++r4) {
-                        const int mt = r4 >> 2, q = 4 * (r4 & 3);
-                        xs[r4 * 64] = f32x4{acc[mt][q], acc[mt][q + 1], acc[mt][q + 2], acc[mt][q + 3]};
-                    }
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int mt = r4 >> 1, q = 8 * (kh ^ 1) + 4 * (r4 & 1);
+                    xs[r4 * 64] = f32x4{acc[mt][q], acc[mt][q + 1], acc[mt][q + 2], acc[mt][q + 3]};
                 }
             }
             WS_STAMP(j, 2);

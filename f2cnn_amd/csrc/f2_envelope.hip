@@ -552,9 +552,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
         flat.reserve(list_elems);
         for (auto& g : groups) flat.insert(flat.end(), g.begin(), g.end());
         F2_TRY(f2_reserve(ctx, ctx->work2, sizeof(int) * flat.size()));
-        F2_HIP(ctx, hipMemcpyAsync(ctx->work2.ptr, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice,
-                                   ctx->stream));
-        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        F2_TRY(f2_upload_async(ctx, ctx->work2.ptr, flat.data(), sizeof(int) * flat.size()));
         d_lists = (int*)ctx->work2.ptr;
     }
     size_t pos = 0;

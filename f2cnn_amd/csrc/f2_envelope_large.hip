@@ -175,8 +175,7 @@ int ensure_large_tables(f2_ctx* ctx, int log2h, f2_scratch& slot) {
         host[(size_t)(H + k)] = {(F)cosl(ang), (F)(-sinl(ang))};
     }
     F2_TRY(f2_reserve(ctx, slot, sizeof(cpx<F>) * host.size()));
-    F2_HIP(ctx, hipMemcpyAsync(slot.ptr, host.data(), sizeof(cpx<F>) * host.size(), hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    F2_TRY(f2_upload_async(ctx, slot.ptr, host.data(), sizeof(cpx<F>) * host.size()));
     return F2_OK;
 }
 

@@ -279,8 +279,7 @@ int ensure_pair_tables(f2_ctx* ctx, f2_scratch& slot) {
         host[(size_t)HS + j] = {(float)cosl(ang), (float)(-sinl(ang))};
     }
     F2_TRY(f2_reserve(ctx, slot, sizeof(cpx<float>) * host.size()));
-    F2_HIP(ctx, hipMemcpyAsync(slot.ptr, host.data(), sizeof(cpx<float>) * host.size(), hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    F2_TRY(f2_upload_async(ctx, slot.ptr, host.data(), sizeof(cpx<float>) * host.size()));
     return F2_OK;
 }
 
@@ -298,8 +297,7 @@ int launch_pair(f2_ctx* ctx, const double* d_gfb, double* d_env, const int64_t* 
         // (same batch shape as the previous call: the device copy is still valid and the call only enqueues)
         list_host.clear();
         F2_TRY(f2_reserve(ctx, list, sizeof(int) * (size_t)nutt));
-        F2_HIP(ctx, hipMemcpyAsync(list.ptr, utts, sizeof(int) * (size_t)nutt, hipMemcpyHostToDevice, ctx->stream));
-        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `utts` belongs to the caller
+        F2_TRY(f2_upload_async(ctx, list.ptr, utts, sizeof(int) * (size_t)nutt));
         list_host.assign(utts, utts + nutt);
     }
     PairParams P;

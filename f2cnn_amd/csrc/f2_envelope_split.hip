@@ -248,8 +248,7 @@ int ensure_split_tables(f2_ctx* ctx, int log2h, f2_scratch& slot) {
         host[(size_t)H + H1 + k2] = {(float)cosl(ang), (float)sinl(ang)};
     }
     F2_TRY(f2_reserve(ctx, slot, sizeof(cpx<float>) * host.size()));
-    F2_HIP(ctx, hipMemcpyAsync(slot.ptr, host.data(), sizeof(cpx<float>) * host.size(), hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    F2_TRY(f2_upload_async(ctx, slot.ptr, host.data(), sizeof(cpx<float>) * host.size()));
     return F2_OK;
 }
 
@@ -289,8 +288,7 @@ int f2_launch_envelope_split(f2_ctx* ctx, const double* d_gfb, double* d_env, co
     const int per_group = (int)std::max<size_t>(1, std::min<size_t>((size_t)nutt, SCRATCH_CAP / per_utt));
     F2_TRY(f2_reserve(ctx, ctx->work, per_utt * (size_t)per_group));
     F2_TRY(f2_reserve(ctx, ctx->work3, sizeof(int) * (size_t)nutt));
-    F2_HIP(ctx, hipMemcpyAsync(ctx->work3.ptr, utts, sizeof(int) * (size_t)nutt, hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `utts` belongs to the caller
+    F2_TRY(f2_upload_async(ctx, ctx->work3.ptr, utts, sizeof(int) * (size_t)nutt));
     SplitParams P;
     P.gfb = d_gfb;
     P.env = d_env;

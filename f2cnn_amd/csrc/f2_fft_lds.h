@@ -273,8 +273,7 @@ int ensure_twiddles(f2_ctx* ctx, int log2h, f2_scratch& slot) {
         host.push_back({(F)cosl(ang), (F)(-sinl(ang))});
     }
     F2_TRY(f2_reserve(ctx, slot, sizeof(cpx<F>) * host.size()));
-    F2_HIP(ctx, hipMemcpyAsync(slot.ptr, host.data(), sizeof(cpx<F>) * host.size(), hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    F2_TRY(f2_upload_async(ctx, slot.ptr, host.data(), sizeof(cpx<F>) * host.size()));   // (a local: staged, not waited for)
     return F2_OK;
 }
 

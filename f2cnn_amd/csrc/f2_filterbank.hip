@@ -496,8 +496,7 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
                 std::vector<double> m((size_t)C * 64);
                 for (int c = 0; c < C; ++c) transition_power(&ctx->coefs_host[(size_t)c * 10], sp.L, &m[(size_t)c * 64]);
                 F2_TRY(f2_reserve(ctx, ctx->k1_mtab, sizeof(double) * m.size()));
-                F2_HIP(ctx, hipMemcpyAsync(ctx->k1_mtab.ptr, m.data(), sizeof(double) * m.size(), hipMemcpyHostToDevice, ctx->stream));
-                F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `m` is a local
+                F2_TRY(f2_upload_async(ctx, ctx->k1_mtab.ptr, m.data(), sizeof(double) * m.size()));
                 ctx->k1_mtab_L = sp.L;
                 ctx->k1_mtab_coefs = ctx->coefs_host;
             }
@@ -521,9 +520,7 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
                     for (int g = 0; g < groups; ++g) order[(size_t)i * groups + g] = by_len[(size_t)i] * groups + g;
                 order[(size_t)units] = 0;     // the queue counter
                 F2_TRY(f2_reserve(ctx, ctx->k1_order, sizeof(int) * order.size()));
-                F2_HIP(ctx, hipMemcpyAsync(ctx->k1_order.ptr, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice,
-                                           ctx->stream));
-                F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `order` is a local
+                F2_TRY(f2_upload_async(ctx, ctx->k1_order.ptr, order.data(), sizeof(int) * order.size()));
                 sp.order = (const int*)ctx->k1_order.ptr;
                 sp.queue = (int*)ctx->k1_order.ptr + units;
             }

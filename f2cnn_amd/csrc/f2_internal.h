@@ -90,6 +90,16 @@ struct f2_ctx {
     int opt_cnn_ws = 1;                   // ... with the weights of each wave's role held in registers (f2_cnn_ws.hip; windows of 10 / 11 rows)
     int opt_gather_blocked = 1;           // every-sample windows: logarithm once per sample, blocks of 32 windows (0: one workgroup per window)
     int opt_env_plan4 = 0;                // four-pass plan for every 1 s row (default: three passes where measured faster)
+    // pinned staging of small host -> device uploads (f2_upload_async): a ring of page-locked memory the copies read from,
+    // so that a call with device pointers only enqueues (the caller's / a local's array is copied on the host at once)
+    char* up_ring = nullptr;
+    size_t up_cap = 0, up_head = 0;
+    struct up_span {
+        size_t begin, end;
+        hipEvent_t done;
+    };
+    std::vector<up_span> up_inflight;                  // oldest first
+    std::vector<std::pair<void*, hipEvent_t>> up_big;   // one-off page-locked buffers of large uploads, freed once copied
     f2_scratch flags;      // small device words (error flags)
     int* host_flags = nullptr;  // pinned mirror
 };
@@ -112,6 +122,9 @@ extern char g_f2_err[512];
 
 int f2_fail(f2_ctx* ctx, int code, const char* fmt, ...);
 int f2_reserve(f2_ctx* ctx, f2_scratch& s, size_t bytes);
+// host -> device copy on the context's stream that does not wait for it: the bytes are copied into page-locked staging
+// memory first (ring for small arrays, a one-off buffer for large tables), `src` may be reused at once
+int f2_upload_async(f2_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int f2_upload_offsets(f2_ctx* ctx, const int64_t* offsets, int B);
 int f2_upload_coefs(f2_ctx* ctx, const double* coefs, int C);
 

@@ -58,9 +58,7 @@ int f2_gather_windows(f2_ctx* ctx, const double* env, int C, int64_t N, const in
     const int64_t* d_centers = nullptr;
     if (centers) {
         F2_TRY(f2_reserve(ctx, ctx->work2, sizeof(int64_t) * (size_t)n_windows));
-        F2_HIP(ctx, hipMemcpyAsync(ctx->work2.ptr, centers, sizeof(int64_t) * (size_t)n_windows, hipMemcpyHostToDevice,
-                                   ctx->stream));
-        F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        F2_TRY(f2_upload_async(ctx, ctx->work2.ptr, centers, sizeof(int64_t) * (size_t)n_windows));
         d_centers = (const int64_t*)ctx->work2.ptr;
     }
     const size_t env_bytes = sizeof(double) * (size_t)C * (size_t)N;

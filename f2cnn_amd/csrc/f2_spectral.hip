@@ -1074,12 +1074,12 @@ static int spectral_tables(f2_ctx* ctx, int C, int log2h, f2_spec_tables** out) 
     F2_TRY(f2_reserve(ctx, t.lgroup, sizeof(int) * Lg.size()));
     if (!e64.empty()) {
         F2_TRY(f2_reserve(ctx, t.e64, sizeof(double) * e64.size()));
-        F2_HIP(ctx, hipMemcpyAsync(t.e64.ptr, e64.data(), sizeof(double) * e64.size(), hipMemcpyHostToDevice, ctx->stream));
+        F2_TRY(f2_upload_async(ctx, t.e64.ptr, e64.data(), sizeof(double) * e64.size()));
     }
-    F2_HIP(ctx, hipMemcpyAsync(t.hu.ptr, hu.data(), sizeof(float) * hu.size(), hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipMemcpyAsync(t.e.ptr, e.data(), sizeof(float) * e.size(), hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipMemcpyAsync(t.lgroup.ptr, Lg.data(), sizeof(int) * Lg.size(), hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the sources are locals (one-time table build)
+    // (the sources are locals: staged through page-locked memory, one-off buffers for the large tables)
+    F2_TRY(f2_upload_async(ctx, t.hu.ptr, hu.data(), sizeof(float) * hu.size()));
+    F2_TRY(f2_upload_async(ctx, t.e.ptr, e.data(), sizeof(float) * e.size()));
+    F2_TRY(f2_upload_async(ctx, t.lgroup.ptr, Lg.data(), sizeof(int) * Lg.size()));
     ctx->spec_tabs.push_back(std::move(t));
     *out = &ctx->spec_tabs.back();
     return F2_OK;
@@ -1110,8 +1110,7 @@ static int lowpass_table(f2_ctx* ctx, double a1, double b0, int nt, int sp, Lowp
         tab[4 * (size_t)t + 3] = (float)powl(q, sp * ((lane & 31) + 1));
     }
     F2_TRY(f2_reserve(ctx, slot, sizeof(float) * tab.size()));
-    F2_HIP(ctx, hipMemcpyAsync(slot.ptr, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
-    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `tab` is a local (one-time per cutoff)
+    F2_TRY(f2_upload_async(ctx, slot.ptr, tab.data(), sizeof(float) * tab.size()));
     slot_a1 = a1;
     *d_tab = (const f2_f4*)slot.ptr;
     return F2_OK;

@@ -12,7 +12,11 @@
  *     pointers. Small metadata arrays (offsets, coefs, centers) are ALWAYS host pointers.
  *   - F2_MEM_HOST calls stage through device memory and return when the result is in the host
  *     buffer. F2_MEM_DEVICE calls enqueue on the context's stream and return immediately
- *     (f2_ctx_synchronize() or a stream-ordered consumer to wait).
+ *     (f2_ctx_synchronize() or a stream-ordered consumer to wait): the small per-batch arrays they
+ *     upload (offsets, utterance lists, ...) are staged through page-locked memory owned by the
+ *     context, so a new batch shape does not wait for the stream either. What does wait: a scratch
+ *     buffer that has to grow (the first call of a size), and the calls that hand an error flag of
+ *     the device back (f2_gather_windows with normalisation, f2_eval_*: F2_ERR_NONPOSITIVE).
  *   - ragged batches: utterance b has n_b = offsets[b+1]-offsets[b] samples; its wave starts at
  *     wave + offsets[b]; its (C, n_b) C-order float64 matrix starts at out + C*offsets[b]. For a
  *     uniform batch this is the plain [B][C][N] layout, and each utterance's block is bit-for-bit the
@@ -108,6 +112,7 @@ int f2_event_create(f2_ctx* ctx, void** event);
 int f2_event_destroy(f2_ctx* ctx, void* event);
 int f2_event_record(f2_ctx* ctx, void* event);                 /* on the context's stream */
 int f2_event_elapsed_ms(f2_ctx* ctx, void* start, void* stop, float* ms); /* waits for `stop` */
+int f2_event_query(f2_ctx* ctx, void* event, int* done);       /* does not wait: *done = 1 once the stream has passed it */
 
 /* ---- per-kernel timing (HIP events recorded around every kernel launch on the context's stream) ----
  * Kernel ids: F2_K_* below. f2_prof_get waits for the stream, returns the number of launches of that
