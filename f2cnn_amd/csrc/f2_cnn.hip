@@ -871,9 +871,14 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __re
 // requested before the current chunk's MFMAs and land while they run; the activations are split when they are written to
 // LDS ([row][64] bf16 per piece, pitch + 16 bytes). Weights: w[piece][chunk][ks][h][n (544)][8], k = 64 chunk + 16 ks + 8 h + e.
 constexpr int D1_PITCH16 = D1_KC * 2 + 16;
+// MT = M tiles (32 windows each) per workgroup. With 64 windows (MT = 2) a 14 240-window chunk is 223 x 3 = 669 workgroups for
+// the 512 that are resident at two per CU: a second round one third full. 96 windows (MT = 3): 149 x 3 = 447 workgroups, one
+// round, and every weight fragment feeds nine MFMAs instead of six.
+template <int MT>
 __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_bf16x3(const float* __restrict__ a, const bf16x8* __restrict__ ws,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
                                                                  int K, int64_t n) {
+    constexpr int D1_MT = MT;
     constexpr int ROWS = 32 * D1_MT, NTHR = D1_WAVES * 64;
     constexpr int PER = (ROWS * (D1_KC / 4) + NTHR - 1) / NTHR;      // float4 of a chunk per thread (3, the last partly)
     __shared__ __attribute__((aligned(16))) unsigned char Ah[2][ROWS * D1_PITCH16];
@@ -973,19 +978,38 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_bf16x3(const float* __
     }
 }
 
-// ---- dense2 + softmax + label: one thread per window ----
+// ---- dense2 + softmax + label: eight threads per window ----
+// (one thread per window read its 516-float row with a 2 KB stride between lanes; eight neighbouring lanes now walk a row in
+// 16-byte pieces - 128 contiguous bytes per load instruction and window - and meet through three DPP-free shuffles. The sum is
+// formed in a different order than the oracle's k = 0 .. 515 chain: float32 rounding level, far inside the 2e-5 score tolerance.)
 __global__ __launch_bounds__(256) void k_dense2_softmax(const float* __restrict__ a, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ scores,
                                                         uint8_t* __restrict__ labels, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float* r = a + i * D1;
+    static_assert(D1 % 4 == 0, "rows walked in float4 pieces");
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int part = threadIdx.x & 7;
+    const int64_t row = i < n ? i : n - 1;
+    const float4* r = reinterpret_cast<const float4*>(a + row * D1);
+    const float4* w4 = reinterpret_cast<const float4*>(w);          // (k, class) pairs: two k per float4
     float z0 = 0.f, z1 = 0.f;
-    for (int k = 0; k < D1; ++k) {
-        const float v = r[k];
-        z0 = fmaf(v, w[2 * k], z0);
-        z1 = fmaf(v, w[2 * k + 1], z1);
+    for (int q = part; q < D1 / 4; q += 8) {
+        const float4 v = r[q];
+        const float4 wa = w4[2 * q], wb = w4[2 * q + 1];
+        z0 = fmaf(v.x, wa.x, z0);
+        z1 = fmaf(v.x, wa.y, z1);
+        z0 = fmaf(v.y, wa.z, z0);
+        z1 = fmaf(v.y, wa.w, z1);
+        z0 = fmaf(v.z, wb.x, z0);
+        z1 = fmaf(v.z, wb.y, z1);
+        z0 = fmaf(v.w, wb.z, z0);
+        z1 = fmaf(v.w, wb.w, z1);
     }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        z0 += __shfl_xor(z0, d);
+        z1 += __shfl_xor(z1, d);
+    }
+    if (part != 0 || i >= n) return;
     z0 += bias[0];
     z1 += bias[1];
     const float m = fmaxf(z0, z1);
@@ -1086,14 +1110,16 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
     }
     {
         const dim3 grid((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
+        constexpr int MT16 = 2;   // (3 - 96 windows, one round of workgroups per 14 240-window chunk - measured slower: 0.165 against 0.157 ms)
+        const dim3 grid16((unsigned)((n + 32 * MT16 - 1) / (32 * MT16)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
         if (ctx->opt_cnn_bf16x3 && cnn->blob16)
-            hipLaunchKernelGGL(k_dense1_bf16x3, grid, dim3(D1_WAVES * 64), 0, ctx->stream, a4,
+            hipLaunchKernelGGL(k_dense1_bf16x3<MT16>, grid16, dim3(D1_WAVES * 64), 0, ctx->stream, a4,
                                (const bf16x8*)(cnn->blob16 + cnn->off16[3]), cnn->t(9), a5, d.flat, n);
         else
             hipLaunchKernelGGL(k_dense1_mfma, grid, dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8), cnn->t(9), a5, d.flat, n);
         F2_HIP(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_dense2_softmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a5, cnn->t(10),
+    hipLaunchKernelGGL(k_dense2_softmax, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, ctx->stream, a5, cnn->t(10),
                        cnn->t(11), d_scores, d_labels, n);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_CNN));

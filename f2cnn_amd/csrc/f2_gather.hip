@@ -78,6 +78,7 @@ __global__ __launch_bounds__(GT) void k_gather_windows(const double* __restrict_
 // an 8-byte strided access and takes its logarithm (float64) each time. Here:
 //   k_log_columns:   L[c][t] = ln env[c][t] once per sample (coalesced in t), with the minimum / maximum over each group of 16
 //                    channels - a window's minimum is the minimum of R x groups of those;
+//   k_window_stats:  (ln min, range) of every window from those partial minima, once;
 //   k_eval_windows:  a workgroup = WB consecutive windows x one tap k; it reads, per channel, the WB consecutive values
 //                    L[c][centre_0 + w + step (k - radius)] (one 256-byte run instead of 32 strided reads), normalises with
 //                    the window's (ln min, range) and turns the (window, channel) tile through LDS into 512-byte output rows.
@@ -106,62 +107,66 @@ __global__ __launch_bounds__(256) void k_log_columns(const double* __restrict__ 
     pmax[(size_t)blockIdx.y * (size_t)span + (size_t)j] = mx;
 }
 
-// grid (blocks of WB windows, taps): every workgroup forms the statistics of its WB windows again (R x groups loads per window)
-__global__ __launch_bounds__(256) void k_eval_windows(const double* __restrict__ L, const double* __restrict__ pmin,
-                                                      const double* __restrict__ pmax, int C, int groups, int64_t span,
-                                                      int64_t n_windows, int radius, int step, float* __restrict__ out,
-                                                      int* __restrict__ flag) {
+// (ln min, ln max - ln min, flag) of every window, once (k_eval_windows used to form them again in each of its R workgroups per
+// block of windows: R x groups loads per window and two float64 logarithms, eleven times): stats[3 e .. 3 e + 2]; flag 1 = all
+// values equal or a non-positive value (rows of zeros; the error flag is raised here)
+__global__ __launch_bounds__(256) void k_window_stats(const double* __restrict__ pmin, const double* __restrict__ pmax, int groups,
+                                                      int64_t span, int64_t n_windows, int radius, int step,
+                                                      double* __restrict__ stats, int* __restrict__ flag) {
+    // 32 consecutive windows x 8 lanes per window: lane p of a window takes the (tap, group) pairs p, p + 8, ... (a single
+    // thread walking all 88 serialises as many L2 latencies); for a fixed pair the 32 windows read one 256-byte run
+    const int w = threadIdx.x & 31, p = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + w;
+    const int R = 2 * radius + 1, pairs = R * groups;
+    double mn = INFINITY, mx = -INFINITY;
+    if (e < n_windows) {
+#pragma unroll 4
+        for (int pq = p; pq < pairs; pq += 8) {
+            const int k2 = pq / groups, g = pq - k2 * groups;
+            const size_t at = (size_t)g * (size_t)span + (size_t)(e + (int64_t)step * k2);
+            mn = fmin(mn, pmin[at]);
+            mx = fmax(mx, pmax[at]);
+        }
+    }
+    __shared__ double smn[8][32], smx[8][32];
+    smn[p][w] = mn;
+    smx[p][w] = mx;
+    __syncthreads();
+    if (p != 0 || e >= n_windows) return;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+        mn = fmin(mn, smn[q][w]);
+        mx = fmax(mx, smx[q][w]);
+    }
+    double zero = 0.0;
+    if (!(mn > 0.0)) {   // also catches NaN; the reference raises ValueError
+        atomicOr(flag, 1);
+        zero = 1.0;
+    }
+    if (mn == mx) zero = 1.0;
+    const double lmn = log(mn);
+    stats[3 * e] = lmn;
+    stats[3 * e + 1] = log(mx) - lmn;
+    stats[3 * e + 2] = zero;
+}
+
+// grid (blocks of WB windows, taps)
+__global__ __launch_bounds__(256) void k_eval_windows(const double* __restrict__ L, const double* __restrict__ stats, int C,
+                                                      int64_t span, int64_t n_windows, int radius, int step,
+                                                      float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* tile = reinterpret_cast<float*>(smem_raw);            // [WB][C + 1]
-    __shared__ double s_lmn[WB], s_range[WB];
-    __shared__ int s_zero[WB];
     const int tid = threadIdx.x;
     const int64_t e0 = (int64_t)blockIdx.x * WB;
     const int k = blockIdx.y;
     const int nw = (int)((n_windows - e0) < WB ? (n_windows - e0) : WB);
     const int R = 2 * radius + 1, CP = C + 1;
-    // window e has its centre at span index e + step * radius (k_log_columns started `reach` samples before the first centre).
-    // Its R x groups partial minima are spread over the eight threads that share the window (a single thread walking all of
-    // them serialises ~90 L2 latencies in front of the workgroup's real work).
+    // window e has its centre at span index e + step * radius (k_log_columns started `reach` samples before the first centre)
     const int w = tid & (WB - 1), cc = tid / WB;                 // 8 channel lanes x 32 windows
-    __shared__ double s_pmn[256 / WB][WB], s_pmx[256 / WB][WB];
-    {
-        double mn = INFINITY, mx = -INFINITY;
-        if (w < nw) {
-            const int pairs = R * groups;
-#pragma unroll 4
-            for (int pq = cc; pq < pairs; pq += 256 / WB) {
-                const int k2 = pq / groups, g = pq - k2 * groups;
-                const size_t at = (size_t)g * (size_t)span + (size_t)(e0 + w + (int64_t)step * k2);
-                mn = fmin(mn, pmin[at]);
-                mx = fmax(mx, pmax[at]);
-            }
-        }
-        s_pmn[cc][w] = mn;
-        s_pmx[cc][w] = mx;
-    }
-    __syncthreads();
-    if (tid < WB) {
-        double mn = INFINITY, mx = -INFINITY;
-#pragma unroll
-        for (int q = 0; q < 256 / WB; ++q) {
-            mn = fmin(mn, s_pmn[q][tid]);
-            mx = fmax(mx, s_pmx[q][tid]);
-        }
-        int zero = 0;
-        if (tid < nw && !(mn > 0.0)) {   // also catches NaN; the reference raises ValueError
-            if (k == 0) atomicOr(flag, 1);
-            zero = 1;
-        }
-        if (mn == mx) zero = 1;
-        const double lmn = log(mn);
-        s_lmn[tid] = lmn;
-        s_range[tid] = log(mx) - lmn;
-        s_zero[tid] = zero;
-    }
-    __syncthreads();
-    const double lmn = s_lmn[w], range = s_range[w];
-    const bool zero = s_zero[w] != 0, live = w < nw;
+    const bool live = w < nw;
+    const double* st = stats + 3 * (e0 + (live ? w : 0));
+    const double lmn = st[0], range = st[1];
+    const bool zero = st[2] != 0.0;
     const double* Lk = L + (e0 + w + (int64_t)step * k);
     for (int c = cc; c < C; c += 256 / WB) {
         float o = 0.f;
@@ -182,17 +187,20 @@ static int launch_eval_windows(f2_ctx* ctx, const double* d_env, int C, int64_t 
     const int64_t reach = (int64_t)step * radius;
     const int64_t span = n_windows + 2 * reach;
     const int groups = (C + LCH - 1) / LCH;
-    F2_TRY(f2_reserve(ctx, ctx->gather_log, sizeof(double) * (size_t)span * ((size_t)C + 2 * (size_t)groups)));
+    F2_TRY(f2_reserve(ctx, ctx->gather_log, sizeof(double) * ((size_t)span * ((size_t)C + 2 * (size_t)groups) + 3 * (size_t)n_windows)));
     double* L = (double*)ctx->gather_log.ptr;
     double* pmin = L + (size_t)span * (size_t)C;
     double* pmax = pmin + (size_t)span * (size_t)groups;
+    double* stats = pmax + (size_t)span * (size_t)groups;
     hipLaunchKernelGGL(k_log_columns, dim3((unsigned)((span + 255) / 256), (unsigned)groups), dim3(256), 0, ctx->stream, d_env, C, N,
                        first_center - reach, span, L, pmin, pmax);
     F2_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_window_stats, dim3((unsigned)((n_windows + 31) / 32)), dim3(256), 0, ctx->stream, (const double*)pmin,
+                       (const double*)pmax, groups, span, n_windows, radius, step, stats, d_flag);
+    F2_HIP(ctx, hipGetLastError());
     const size_t lds = sizeof(float) * WB * ((size_t)C + 1);
     hipLaunchKernelGGL(k_eval_windows, dim3((unsigned)((n_windows + WB - 1) / WB), (unsigned)(2 * radius + 1)), dim3(256), lds,
-                       ctx->stream, (const double*)L, (const double*)pmin, (const double*)pmax, C, groups, span, n_windows, radius,
-                       step, d_out, d_flag);
+                       ctx->stream, (const double*)L, (const double*)stats, C, span, n_windows, radius, step, d_out);
     F2_HIP(ctx, hipGetLastError());
     return F2_OK;
 }

@@ -39,11 +39,45 @@ def _parse_cpulist(text):
     return cpus
 
 
+def _pci_numa_node(sysfs, bdf):
+    try:
+        return int(open(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
 def gpu_numa_nodes(sysfs="/sys"):
-    """NUMA node of every AMD GPU of the host, in PCI address order (the order HIP enumerates them in), read from sysfs
-    without touching the GPU: [(pci address, node)], node -1 where the platform reports none."""
-    base = os.path.join(sysfs, "bus", "pci", "devices")
+    """NUMA node of every AMD GPU of the host in the order the ROCm runtime enumerates them, read from sysfs without touching
+    the GPU: [(pci address, node)], node -1 where the platform reports none. The order comes from the KFD topology
+    (/sys/class/kfd/kfd/topology/nodes/<i>/properties: nodes with SIMDs are GPUs, `domain` + `location_id` give the PCI
+    function) - HIP device i is the i-th of them; hosts without that tree fall back to the AMD display / accelerator
+    functions in PCI address order, which is NOT guaranteed to be the enumeration order (round-3 advisor finding):
+    pin_to_gpu_numa_node only trusts it when there is a single candidate node anyway."""
+    kfd = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
     out = []
+    try:
+        nodes = sorted((int(n) for n in os.listdir(kfd) if n.isdigit()))
+    except OSError:
+        nodes = []
+    for n in nodes:
+        props = {}
+        try:
+            for line in open(os.path.join(kfd, str(n), "properties")):
+                k, _, v = line.strip().partition(" ")
+                props[k] = v
+        except OSError:
+            continue
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                                   # a CPU node
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        except (KeyError, ValueError):
+            continue
+        bdf = "{:04x}:{:02x}:{:02x}.{:x}".format(dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 0x7)
+        out.append((bdf, _pci_numa_node(sysfs, bdf)))
+    if out:
+        return out
+    base = os.path.join(sysfs, "bus", "pci", "devices")
     try:
         names = sorted(os.listdir(base))
     except OSError:
@@ -58,32 +92,38 @@ def gpu_numa_nodes(sysfs="/sys"):
         # display controllers (0x03xxxx) and processing accelerators (0x12xxxx) of vendor 0x1002
         if vendor != "0x1002" or not (cls.startswith("0x03") or cls.startswith("0x12")):
             continue
-        try:
-            node = int(open(os.path.join(dev, "numa_node")).read().strip())
-        except (OSError, ValueError):
-            node = -1
-        out.append((bdf, node))
+        out.append((bdf, _pci_numa_node(sysfs, bdf)))
     return out
+
+
+def _kfd_order_known(sysfs):
+    return os.path.isdir(os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes"))
 
 
 def pin_to_gpu_numa_node(local=None, sysfs="/sys", apply=True):
     """Restrict this process to the cores of the NUMA node its GPU hangs off, BEFORE the first GPU call: the staging
     buffers it then allocates (first touch) and its reader / writer threads stay next to the device's PCIe root. With
     eight ranks on a two-socket host the alternative is that half of them copy across the socket link.
-    `local` = index among the visible GPUs (default: local_device(), mapped through HIP_VISIBLE_DEVICES /
-    ROCR_VISIBLE_DEVICES when they list plain indices). Returns {"gpu", "numa_node", "cpus"} or None when the platform
-    gives no answer (one node, no sysfs entry, affinity calls unavailable): then nothing is changed."""
+    `local` = index among the visible GPUs (default: local_device()); ROCR_VISIBLE_DEVICES filters the runtime's list first
+    and HIP_VISIBLE_DEVICES then indexes what is left - both are applied, in that order, when they list plain indices.
+    Returns {"gpu", "numa_node", "cpus"} or None - and changes nothing - whenever the answer is not certain: no sysfs entry,
+    a visibility variable that is not a list of indices (UUIDs), an index out of range, affinity calls unavailable, or an
+    enumeration order that had to be guessed from PCI addresses while the GPUs sit on different nodes (a wrong guess would
+    pin the rank to the far socket, the copies this function exists to avoid)."""
     if not hasattr(os, "sched_setaffinity"):
         return None
     local = local_device() if local is None else int(local)
     gpus = gpu_numa_nodes(sysfs)
-    visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
-    if visible:
-        try:
-            idx = [int(v) for v in visible.split(",") if v.strip() != ""]
-            gpus = [gpus[i] for i in idx]
-        except (ValueError, IndexError):
-            return None
+    if not _kfd_order_known(sysfs) and len({node for _, node in gpus}) > 1:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        visible = os.environ.get(var)
+        if visible:
+            try:
+                idx = [int(v) for v in visible.split(",") if v.strip() != ""]
+                gpus = [gpus[i] for i in idx]
+            except (ValueError, IndexError):
+                return None
     if not (0 <= local < len(gpus)):
         return None
     bdf, node = gpus[local]

@@ -168,33 +168,44 @@ def RMS(signal):
     return numpy.sqrt(numpy.mean(numpy.square(numpy.asarray(signal, dtype=numpy.float64))))
 
 
+def _noisy_copy_paths(file, SNRdB):
+    """Where `cnn evalnoise` puts its outputs (reference layout, Evaluating.py:203-206): OutputWavFiles/addedNoise/<stem><SNR>dB.*"""
+    stem = os.path.basename(os.path.splitext(file)[0])
+    target = os.path.join('OutputWavFiles', 'addedNoise', '{}{}dB'.format(stem, SNRdB))
+    return os.path.splitext(file)[0], target
+
+
+def add_gaussian_noise(wave, SNRdB, rng=None):
+    """wave + N(0, sigma^2), sigma = RMS(wave) / 10^(SNRdB / 10) - the reference's scaling (Evaluating.py:199), which divides
+    by the POWER ratio where an amplitude ratio would be 10^(SNRdB / 20); reproduced, not corrected. float64 out."""
+    sigma = RMS(wave) / SNRdbToSNRlinear(SNRdB)
+    draw = (rng or numpy.random).normal
+    return numpy.asarray(wave, dtype=numpy.float64) + draw(scale=sigma, size=len(wave))
+
+
 def EvaluateWithNoise(file, LPF=False, CUTOFF=100, model='last_trained_model', CENTER_FREQUENCIES=None,
                       FILTERBANK_COEFFICIENTS=None, SNRdB=-3, rng=None):
-    """`cnn evalnoise`: add Gaussian noise of standard deviation RMS(wave)/10^(SNRdB/10) (the reference's scaling,
-    Evaluating.py:199), save the noisy WAV under OutputWavFiles/addedNoise/, and evaluate the float64 waveform."""
-    from shutil import copyfile
+    """`cnn evalnoise` (reference: scripts/CNN/Evaluating.py:193-221): the file plus Gaussian noise at the requested level is
+    written next to copies of its annotation files under OutputWavFiles/addedNoise/ and the float64 waveform is evaluated by
+    the device pipeline. Returns (scores, labels) and also leaves them in <target>.F2CNN.npz; `rng` (a numpy Generator or
+    RandomState) makes the noise reproducible - the reference draws from the global numpy state."""
+    import shutil
     from scipy.io import wavfile
     print("File:\t\t{}".format(file))
-    print("Appyling gaussian noise, new SNR is {SNR}dB".format(SNR=SNRdB))
-    framerate, wavList = GetArrayFromWAV(file)
-    rng = rng or numpy.random
-    noise = rng.normal(scale=RMS(wavList) / SNRdbToSNRlinear(SNRdB), size=wavList.shape[0])
-    output = noise + wavList
-    os.makedirs(os.path.join('OutputWavFiles', 'addedNoise'), exist_ok=True)
-    baseName = os.path.join('OutputWavFiles', 'addedNoise',
-                            os.path.split(os.path.splitext(file)[0])[1]) + '{SNR}dB'.format(SNR=SNRdB)
-    newPath = baseName + '.WAV'
-    srcBasename = os.path.splitext(file)[0]
-    wavfile.write(newPath, framerate, output)
+    print("Appyling gaussian noise, new SNR is {SNR}dB".format(SNR=SNRdB))      # (the reference's wording, kept for log parsers)
+    framerate, clean = GetArrayFromWAV(file)
+    noisy = add_gaussian_noise(clean, SNRdB, rng)
+    source, target = _noisy_copy_paths(file, SNRdB)
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    wavfile.write(target + '.WAV', framerate, noisy)
+    # annotation files travel with the audio where they exist (the reference gives up on all three at the first missing one)
     for ext in ('.FB', '.PHN', '.WRD'):
-        try:
-            copyfile(srcBasename + ext, baseName + ext)
-        except FileNotFoundError:
-            pass
-    print('New noisy WAVE file saved as', newPath)
-    scores, labels = EvaluateOneWavArray(output, framerate, newPath, model=model, LPF=LPF, CUTOFF=CUTOFF,
+        if os.path.exists(source + ext):
+            shutil.copyfile(source + ext, target + ext)
+    print('New noisy WAVE file saved as', target + '.WAV')
+    scores, labels = EvaluateOneWavArray(noisy, framerate, target + '.WAV', model=model, LPF=LPF, CUTOFF=CUTOFF,
                                          CENTER_FREQUENCIES=CENTER_FREQUENCIES,
                                          FILTERBANK_COEFFICIENTS=FILTERBANK_COEFFICIENTS)
-    numpy.savez(baseName + '.F2CNN.npz', scores=scores, labels=labels)
+    numpy.savez(target + '.F2CNN.npz', scores=scores, labels=labels)
     print("\t\t{}\tdone !".format(file))
     return scores, labels

@@ -24,7 +24,8 @@ def test_erb_space_defaults():
 
 def test_rank_placement_from_a_sysfs_tree(tmp_path, monkeypatch):
     """pin_to_gpu_numa_node reads the GPU -> NUMA node -> cpulist chain from sysfs (here: a fabricated two-socket tree
-    with four GPUs, a network card and a GPU without a node) and never touches the device."""
+    with four GPUs, a network card and a GPU without a node) and never touches the device. The enumeration order is the
+    KFD topology's, not the PCI address order (round-3 advisor finding); without that tree a multi-node host is left alone."""
     import os
     from f2cnn_amd import runtime
 
@@ -48,14 +49,38 @@ def test_rank_placement_from_a_sysfs_tree(tmp_path, monkeypatch):
         (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
     monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
     monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    # no KFD topology: PCI address order is only a guess, and the GPUs sit on two nodes -> nothing is pinned
     assert [n for _, n in runtime.gpu_numa_nodes(str(tmp_path))] == [0, 0, 1, -1]
-    got = runtime.pin_to_gpu_numa_node(2, sysfs=str(tmp_path), apply=False)
+    assert runtime.pin_to_gpu_numa_node(2, sysfs=str(tmp_path), apply=False) is None
+
+    # the runtime's own order: two CPU nodes, then the GPUs - deliberately NOT in PCI address order
+    def kfd(index, simds, bdf=None):
+        d = tmp_path / "class" / "kfd" / "kfd" / "topology" / "nodes" / str(index)
+        d.mkdir(parents=True)
+        text = "cpu_cores_count {}\nsimd_count {}\n".format(0 if simds else 32, simds)
+        if bdf:
+            dom, bus, rest = bdf.split(":")
+            devn, fn = rest.split(".")
+            text += "domain {}\nlocation_id {}\n".format(int(dom, 16), (int(bus, 16) << 8) | (int(devn, 16) << 3) | int(fn, 16))
+        (d / "properties").write_text(text)
+    kfd(0, 0)
+    kfd(1, 0)
+    for index, bdf in ((2, "0000:85:00.0"), (3, "0000:05:00.0"), (4, "0000:95:00.0"), (5, "0000:15:00.0")):
+        kfd(index, 1024, bdf)
+    assert runtime.gpu_numa_nodes(str(tmp_path)) == [("0000:85:00.0", 1), ("0000:05:00.0", 0), ("0000:95:00.0", -1), ("0000:15:00.0", 0)]
+    got = runtime.pin_to_gpu_numa_node(0, sysfs=str(tmp_path), apply=False)
     assert got == {"gpu": "0000:85:00.0", "numa_node": 1, "cpus": len(have[half:] or have[:1])}
-    assert runtime.pin_to_gpu_numa_node(3, sysfs=str(tmp_path), apply=False) is None        # no node reported
+    assert runtime.pin_to_gpu_numa_node(2, sysfs=str(tmp_path), apply=False) is None        # no node reported
     assert runtime.pin_to_gpu_numa_node(7, sysfs=str(tmp_path), apply=False) is None        # no such GPU
-    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
-    assert runtime.pin_to_gpu_numa_node(0, sysfs=str(tmp_path), apply=False)["numa_node"] == 1
-    assert runtime.pin_to_gpu_numa_node(1, sysfs=str(tmp_path), apply=False)["numa_node"] == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3,0")
+    assert runtime.pin_to_gpu_numa_node(0, sysfs=str(tmp_path), apply=False)["numa_node"] == 0
+    assert runtime.pin_to_gpu_numa_node(1, sysfs=str(tmp_path), apply=False)["numa_node"] == 1
+    # both variables set: ROCR_VISIBLE_DEVICES filters the runtime's list first, HIP_VISIBLE_DEVICES indexes the rest
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1,3,0")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2")
+    assert runtime.pin_to_gpu_numa_node(0, sysfs=str(tmp_path), apply=False)["gpu"] == "0000:85:00.0"
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "GPU-deadbeef")                                # not an index list: no answer
+    assert runtime.pin_to_gpu_numa_node(0, sysfs=str(tmp_path), apply=False) is None
     assert runtime._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
     assert sorted(os.sched_getaffinity(0)) == have                                          # apply=False changed nothing
 
