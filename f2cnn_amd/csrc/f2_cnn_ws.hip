@@ -40,6 +40,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C1 = 32, C2 = 32, C3 = 64, C4 = 64;
 constexpr int PW = 34;            // patch width: 32 output columns + 2
@@ -203,7 +205,8 @@ constexpr int XIN_BYTES = ((XIN * 4 + 255) / 256) * 256;
 constexpr int CTAB = 2 * XW + 2;                   // floats: 1, 0, 0, ... - what the upper lane half reads in place of taps 1 .. 7,
 constexpr int CTAB_BYTES = ((CTAB * 4 + 255) / 256) * 256;   // one copy behind EACH raw-input buffer (same offset from either base)
 constexpr int XIN_STRIDE = XIN_BYTES + CTAB_BYTES;
-constexpr size_t LDS12 = 2 * (size_t)XIN_STRIDE + 2 * (size_t)P12_BUF;   // (raw input + table) x 2 (LDS-DMA targets first), patches x 2
+constexpr int W1_BYTES = 2 * 64 * 16;               // conv1's A operand (W1^T, bias row), hi and lo piece, 16 bytes per lane
+constexpr size_t LDS12 = 2 * (size_t)XIN_STRIDE + 2 * (size_t)P12_BUF + W1_BYTES;   // (raw input + table) x 2 (LDS-DMA targets first), patches x 2, W1
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // global -> LDS without registers (global_load_lds_dword / _dwordx4; LDS address = `lds_addr` + lane x size, wave-uniform), as
@@ -273,8 +276,12 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
         w1h[j] = vh;
         w1l[j] = (__bf16)(v - (float)vh);
     }
-    pin(w1h);
-    pin(w1l);
+    // (fetched from LDS for every pixel block: eight registers that do not have to live through the matrix loop)
+    unsigned char* const ldsW1 = ldsP + 2 * P12_BUF + lane * 16;
+    if (wave == 0) {
+        *reinterpret_cast<bf16x8*>(ldsW1) = w1h;
+        *reinterpret_cast<bf16x8*>(ldsW1 + 64 * 16) = w1l;
+    }
 
     // conv2: this lane's pixel (accumulator row i): image row 2 rp + (i >> 4), column 16 ch + (i & 15)
     const int row2 = 2 * rp + (i >> 4), col2 = 16 * ch + (i & 15);
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
         const int pr = ec / PW, pc = ec - pr * PW;
         xoff0[tt] = (pr * XW + pc + (h ? 2 * XW + 2 : 0)) * 4;
         xoff1[tt] = h ? XIN_BYTES - 4 : (pr * XW + pc) * 4;           // (upper half: table[-1], so that slot j = 1 reads table[0])
-        poff[tt] = e < P12_PIX ? c32_off(pr, pc, 0) + 8 * h : -1;       // channels 8 g + 4 h ..: plane g >> 1, at poff ^ ((g & 1) << 4)
+        poff[tt] = e < P12_PIX ? c32_off(pr, pc, h) : -1;               // this lane's 16-byte chunk of the pixel in either plane
     }
     const int nblk = wave + 8 < P12_TILES ? 2 : 1;
     // LDS-DMA pieces of this wave (wave-uniform)
@@ -296,6 +303,16 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
 
     // ---- the VALU / LDS work of an iteration, in pieces that ride in the gaps of the matrix loop ----
     // LDS-DMA piece m (0, 1) of the raw input of task t_(k+2): element e = (row r, column c) of the 12 x 36 region, a dword per lane
+    // (per lane and piece ONE packed register, unpacked behind an opaque copy on every use: left to itself the compiler hoists the
+    // row pointers of both pieces out of the tile loop - four registers it then spills and re-loads behind a vmcnt(0))
+    unsigned dpk[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int piece = m == 0 ? dma0 : dma1;
+        const int e = 64 * max(piece, 0) + lane;
+        const int r = e / XW, c = e - r * XW, yi = r - 1;
+        dpk[m] = (e < XIN && (unsigned)yi < (unsigned)Hin) ? (unsigned)(yi * Win + c - 1 + Win) | ((unsigned)c << 24) : 0x80000000u | (e < XIN ? 0u : 0x40000000u);
+    }
     auto dma_piece = [&](int k, int m) {
         const int piece = m == 0 ? dma0 : dma1;
         if (piece < 0) return;                                 // wave-uniform
@@ -304,17 +321,18 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
         const int x0 = 32 * (int)xi0;
         const float* img = x + (size_t)win * (size_t)(Hin * Win);
         const unsigned xb = __builtin_amdgcn_readfirstlane(lds_address(lds) + (k & 1) * XIN_STRIDE + 256 * piece);
-        const int e = 64 * piece + lane;
-        const int r = e / XW, c = e - r * XW;
-        const int yi = r - 1, xi = x0 - 1 + c;
-        const float* src = ((unsigned)yi < (unsigned)Hin && (unsigned)xi < (unsigned)Win) ? img + yi * Win + xi : zeros;
-        if (e < XIN) dma4_to_lds(src, xb);
+        unsigned q = dpk[m];
+        asm volatile("" : "+v"(q));
+        const bool ok = (int)q >= 0 && (unsigned)(x0 - 1 + (int)(q >> 24)) < (unsigned)Win;
+        const float* src = ok ? img + ((int)(q & 0xffffffu) - Win + x0) : zeros;
+        if (!(q & 0x40000000u)) dma4_to_lds(src, xb);
     };
     // conv1 of pixel block tt of task t_(k+1), stage c: 0 taps from LDS, 1 split, 2 the three MFMAs, 3 .. 6 ReLU + split + store of
     // channels 8 g + 4 h .. + 3 (g = c - 3)
     float xv[8];
     bf16x8 xh, xl;
     f32x16 a1;
+    u32x2 kh, kl;
     auto conv1_stage = [&](int k, int tt, int c) {
         const unsigned char* xin = lds + ((k + 1) & 1) * XIN_STRIDE;
         unsigned char* ph = ldsP + ((k + 1) & 1) * P12_BUF;
@@ -325,6 +343,8 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
 #pragma unroll
             for (int j = 1; j < 8; ++j) xv[j] = x1p[(j / 3) * XW + (j % 3)];
         } else if (c == 1) {
+            w1h = *reinterpret_cast<const bf16x8*>(ldsW1);
+            w1l = *reinterpret_cast<const bf16x8*>(ldsW1 + 64 * 16);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const __bf16 vh = (__bf16)xv[j];
@@ -337,13 +357,29 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
             a1 = MFMA16(w1l, xh, a1);
             a1 = MFMA16(w1h, xl, a1);
             a1 = MFMA16(w1h, xh, a1);
-        } else if (poff[tt] >= 0) {
+        } else {
+            // quads g = 2 G, 2 G + 1 are the two 16-byte chunks of plane G, each half in one lane of the pair (i, h): after
+            // v_permlane32_swap (upper lanes of the first operand <-> lower lanes of the second) lane (i, 0) holds chunk 0 and
+            // lane (i, 1) chunk 1 whole - one 16-byte store per lane, plane and piece instead of two 8-byte stores with a
+            // 32-byte lane stride (four-way bank conflicts: 37 % of the kernel's LDS cycles)
             const int g = c - 3;
             bf16x4 vh, vl;
             split4(relu(a1[4 * g]), relu(a1[4 * g + 1]), relu(a1[4 * g + 2]), relu(a1[4 * g + 3]), vh, vl);
-            const int off = (g >> 1) * P12_PLANE + (poff[tt] ^ ((g & 1) << 4));
-            *reinterpret_cast<bf16x4*>(ph + off) = vh;
-            *reinterpret_cast<bf16x4*>(ph + P12_PIECE + off) = vl;
+            const u32x2 bh = __builtin_bit_cast(u32x2, vh), bl = __builtin_bit_cast(u32x2, vl);
+            if ((g & 1) == 0) {
+                kh = bh;
+                kl = bl;
+            } else {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(kh.x, bh.x, false, false);   // {first operand, second operand} afterwards
+                const auto s1 = __builtin_amdgcn_permlane32_swap(kh.y, bh.y, false, false);
+                const auto s2 = __builtin_amdgcn_permlane32_swap(kl.x, bl.x, false, false);
+                const auto s3 = __builtin_amdgcn_permlane32_swap(kl.y, bl.y, false, false);
+                if (poff[tt] >= 0) {
+                    const int off = (g >> 1) * P12_PLANE + poff[tt];
+                    *reinterpret_cast<u32x4*>(ph + off) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    *reinterpret_cast<u32x4*>(ph + P12_PIECE + off) = u32x4{s2[0], s3[0], s2[1], s3[1]};
+                }
+            }
         }
     };
     // conv2 + pool of this wave's 2 x 16 pixels of task t_k, `fill` riding in the matrix loop. The four pooled maxima stay in
@@ -385,17 +421,20 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
         if (k >= 0 && k + 2 < nloc) {
             // steady state: the LDS-DMA pieces (first: they have the whole loop to land), the conv1 stages and the stores of the
             // previous task sit behind the steps of the matrix loop
+            // (the stores first: `s_waitcnt vmcnt(0)` in front of the barrier also waits for their write acknowledgements - behind
+            // the last steps of the loop they cost every wave ~350 cycles there)
             if (nblk == 2) {
                 conv2(k, [&](int f) {
-                    if (f < 7) conv1_stage(k, 0, f);
-                    else if (f < 14) conv1_stage(k, 1, f - 7);
-                    else if (f < 16 && pending) store_pooled(k - 1, 2 * (f - 14));
+                    if (f < 2) {
+                        if (pending) store_pooled(k - 1, 2 * f);
+                    } else if (f < 9) conv1_stage(k, 0, f - 2);
+                    else if (f < 16) conv1_stage(k, 1, f - 9);
                 });
             } else {
                 conv2(k, [&](int f) {
                     if (f < 2) dma_piece(k, f);
                     else if (f < 16 && (f & 1) == 0) conv1_stage(k, 0, (f - 2) >> 1);
-                    else if ((f == 15 || f == 17) && pending) store_pooled(k - 1, f - 15);
+                    else if ((f == 3 || f == 5) && pending) store_pooled(k - 1, f - 3);
                 });
             }
         } else {
