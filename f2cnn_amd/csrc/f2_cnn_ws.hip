@@ -67,8 +67,9 @@ __device__ __forceinline__ void split4(const float v0, const float v1, const flo
     lo = bf16x4{(__bf16)(v0 - (float)h0), (__bf16)(v1 - (float)h1), (__bf16)(v2 - (float)h2), (__bf16)(v3 - (float)h3)};
 }
 
-// ReLU as ONE instruction (fmaxf canonicalises its operand first: two v_max_f32 per value)
-__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
+// ReLU as ONE instruction: integer max with 0 on the bit pattern (negative floats are negative integers; fmaxf and v_med3 alike come
+// out of this compiler as a canonicalising v_max(v, v) followed by v_max(0, v))
+__device__ __forceinline__ float relu(float v) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), 0)); }
 
 // a value the compiler must keep in a register from here on (it cannot re-load or re-derive it inside the tile loop)
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
@@ -200,7 +201,7 @@ constexpr int P12_BUF = 2 * P12_PIECE;             // hi + lo
 constexpr int P12_TILES = (P12_PIX + 31) / 32;     // 11 conv1 blocks of 32 pixels: wave w takes block w, waves 0-2 also block 8 + w
 constexpr int XR = P12_ROWS + 2, XW = PW + 2;      // raw input region of a task: rows -1 .. 10, columns x0 - 1 .. x0 + 34
 constexpr int XIN = XR * XW;                       // 432 floats
-static_assert((XIN + 63) / 64 == 7, "LDS-DMA pieces of the raw input: waves 3-7 take piece w - 3, waves 3, 4 also w + 2");
+static_assert((XIN + 63) / 64 == 7, "LDS-DMA pieces of the raw input: waves 4-7 take piece w - 4, waves 4-6 also piece w");
 constexpr int XIN_BYTES = ((XIN * 4 + 255) / 256) * 256;
 constexpr int CTAB = 2 * XW + 2;                   // floats: 1, 0, 0, ... - what the upper lane half reads in place of taps 1 .. 7,
 constexpr int CTAB_BYTES = ((CTAB * 4 + 255) / 256) * 256;   // one copy behind EACH raw-input buffer (same offset from either base)
@@ -287,18 +288,22 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
     const int row2 = 2 * rp + (i >> 4), col2 = 16 * ch + (i & 15);
     // conv1: pixel e of block b is patch pixel 32 b + i; lane (i, h) supplies taps 8 h + j: the lower half reads taps 0 .. 7 at
     // xin[(pr + dy) XW + pc + dx], the upper half tap 8 and then the table 1, 0, 0, ... through the same immediate offsets
+    // Blocks by wave: the SIMD's issue arbitration favours its older wave (0-3), which finishes its matrix loop ~1000 cycles before
+    // the younger one (4-7) when both carry the same load - so waves 0-3 take two blocks each (0 .. 7), waves 4-6 one (8 .. 10; wave 7 an empty one) and
+    // waves 4-7 the LDS-DMA pieces.
     int xoff0[2], xoff1[2], poff[2];       // byte offsets: tap slot 0, tap slots 1..7 (from xin[0]), patch pixel
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-        const int e = 32 * (wave + 8 * tt) + i, ec = min(e, P12_PIX - 1);
+        const int blk = wave < 4 ? wave + 4 * tt : wave + 4;
+        const int e = 32 * blk + i, ec = min(e, P12_PIX - 1);
         const int pr = ec / PW, pc = ec - pr * PW;
         xoff0[tt] = (pr * XW + pc + (h ? 2 * XW + 2 : 0)) * 4;
         xoff1[tt] = h ? XIN_BYTES - 4 : (pr * XW + pc) * 4;           // (upper half: table[-1], so that slot j = 1 reads table[0])
         poff[tt] = e < P12_PIX ? c32_off(pr, pc, h) : -1;               // this lane's 16-byte chunk of the pixel in either plane
     }
-    const int nblk = wave + 8 < P12_TILES ? 2 : 1;
+    const int nblk = wave < 4 ? 2 : 1;        // (wave 7: a block of pixels beyond the patch - computed, never stored)
     // LDS-DMA pieces of this wave (wave-uniform)
-    const int dma0 = wave >= 3 ? wave - 3 : -1, dma1 = (wave == 3 || wave == 4) ? wave + 2 : -1;
+    const int dma0 = wave >= 4 ? wave - 4 : -1, dma1 = (wave >= 4 && wave < 7) ? wave : -1;
     __syncthreads();
 
     // ---- the VALU / LDS work of an iteration, in pieces that ride in the gaps of the matrix loop ----
@@ -431,10 +436,15 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
                     else if (f < 16) conv1_stage(k, 1, f - 9);
                 });
             } else {
+#ifndef F2_B_PRIO_STEPS
+#define F2_B_PRIO_STEPS 0
+#endif
+                if (F2_B_PRIO_STEPS > 0) __builtin_amdgcn_s_setprio(1);
                 conv2(k, [&](int f) {
                     if (f < 2) dma_piece(k, f);
                     else if (f < 16 && (f & 1) == 0) conv1_stage(k, 0, (f - 2) >> 1);
                     else if ((f == 3 || f == 5) && pending) store_pooled(k - 1, f - 3);
+                    if (F2_B_PRIO_STEPS > 0 && f == F2_B_PRIO_STEPS - 1) __builtin_amdgcn_s_setprio(0);
                 });
             }
         } else {
