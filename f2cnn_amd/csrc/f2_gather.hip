@@ -96,11 +96,25 @@ __global__ __launch_bounds__(256) void k_log_columns(const double* __restrict__ 
     const int c0 = blockIdx.y * LCH, c1 = min(C, c0 + LCH);
     double mn = INFINITY, mx = -INFINITY;
     if (t >= 0 && t < N) {
-        for (int c = c0; c < c1; ++c) {
-            const double v = env[(size_t)c * (size_t)N + (size_t)t];
-            L[(size_t)c * (size_t)span + (size_t)j] = log(v);
-            mn = fmin(mn, v);
-            mx = fmax(mx, v);
+        if (c1 - c0 == LCH) {
+            // (all sixteen loads in flight before the first logarithm: the dependent load -> log -> store chain per channel was
+            // sixteen memory latencies long)
+            double v[LCH];
+#pragma unroll
+            for (int u = 0; u < LCH; ++u) v[u] = env[(size_t)(c0 + u) * (size_t)N + (size_t)t];
+#pragma unroll
+            for (int u = 0; u < LCH; ++u) {
+                L[(size_t)(c0 + u) * (size_t)span + (size_t)j] = log(v[u]);
+                mn = fmin(mn, v[u]);
+                mx = fmax(mx, v[u]);
+            }
+        } else {
+            for (int c = c0; c < c1; ++c) {
+                const double v = env[(size_t)c * (size_t)N + (size_t)t];
+                L[(size_t)c * (size_t)span + (size_t)j] = log(v);
+                mn = fmin(mn, v);
+                mx = fmax(mx, v);
+            }
         }
     }
     pmin[(size_t)blockIdx.y * (size_t)span + (size_t)j] = mn;     // minimum / maximum over this group's channels
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(256) void k_log_columns(const double* __restrict__ 
 }
 
 // (ln min, ln max - ln min, flag) of every window, once (k_eval_windows used to form them again in each of its R workgroups per
-// block of windows: R x groups loads per window and two float64 logarithms, eleven times): stats[3 e .. 3 e + 2]; flag 1 = all
+// block of windows: R x groups loads per window and two float64 logarithms, eleven times): stats[4 e .. 4 e + 3]; flag 1 = all
 // values equal or a non-positive value (rows of zeros; the error flag is raised here)
 __global__ __launch_bounds__(256) void k_window_stats(const double* __restrict__ pmin, const double* __restrict__ pmax, int groups,
                                                       int64_t span, int64_t n_windows, int radius, int step,
@@ -144,10 +158,11 @@ __global__ __launch_bounds__(256) void k_window_stats(const double* __restrict__
         zero = 1.0;
     }
     if (mn == mx) zero = 1.0;
-    const double lmn = log(mn);
-    stats[3 * e] = lmn;
-    stats[3 * e + 1] = log(mx) - lmn;
-    stats[3 * e + 2] = zero;
+    const double lmn = log(mn), range = log(mx) - lmn;
+    stats[4 * e] = lmn;
+    stats[4 * e + 1] = range;
+    stats[4 * e + 2] = zero;
+    stats[4 * e + 3] = 1.0 / range;   // (correctly rounded: k_eval_windows divides by `range` through it)
 }
 
 // grid (blocks of WB windows, taps)
@@ -164,19 +179,41 @@ __global__ __launch_bounds__(256) void k_eval_windows(const double* __restrict__
     // window e has its centre at span index e + step * radius (k_log_columns started `reach` samples before the first centre)
     const int w = tid & (WB - 1), cc = tid / WB;                 // 8 channel lanes x 32 windows
     const bool live = w < nw;
-    const double* st = stats + 3 * (e0 + (live ? w : 0));
-    const double lmn = st[0], range = st[1];
+    const double* st = stats + 4 * (e0 + (live ? w : 0));
+    const double lmn = st[0], range = st[1], rinv = st[3];
     const bool zero = st[2] != 0.0;
     const double* Lk = L + (e0 + w + (int64_t)step * k);
-    for (int c = cc; c < C; c += 256 / WB) {
-        float o = 0.f;
-        if (live && !zero) o = (float)((Lk[(size_t)c * (size_t)span] - lmn) / range);
-        tile[w * CP + c] = o;
+    // (eight loads in flight per thread; a / range, correctly rounded, in three float64 operations instead of the ~12 + v_rcp_f64
+    // of a division: q0 = RN(a rinv) is within an ulp of the quotient, the residual a - q0 range is exact in one fma, and
+    // RN(q0 + residual x rinv) is the rounded quotient - Markstein's correction step with rinv = RN(1 / range); bit-identical to
+    // the per-window kernel's division in test_every_sample_windows_blocked_and_per_window_kernels_agree)
+    constexpr int CL = 256 / WB, UN = 8;
+    for (int c0 = cc; c0 < C; c0 += CL * UN) {
+        double v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) v[u] = (live && c0 + CL * u < C) ? Lk[(size_t)(c0 + CL * u) * (size_t)span] : lmn;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const double a = v[u] - lmn, q0 = a * rinv;
+            const float o = (live && !zero) ? (float)fma(fma(-q0, range, a), rinv, q0) : 0.f;
+            if (c0 + CL * u < C) tile[w * CP + c0 + CL * u] = o;
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < nw * C; idx += 256) {
-        const int ww = idx / C, c = idx - ww * C;
-        out[((size_t)(e0 + ww) * R + k) * (size_t)C + c] = tile[ww * CP + c];
+    float* orow = out + ((size_t)e0 * R + k) * (size_t)C;
+    if ((C & 3) == 0) {
+        // 16 bytes per lane: a window's row of C floats is C / 4 consecutive lanes
+        const int C4 = C >> 2;
+        for (int idx = tid; idx < nw * C4; idx += 256) {
+            const int ww = idx / C4, c = (idx - ww * C4) * 4;
+            const float* t = tile + ww * CP + c;
+            *reinterpret_cast<float4*>(orow + (size_t)ww * R * C + c) = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    } else {
+        for (int idx = tid; idx < nw * C; idx += 256) {
+            const int ww = idx / C, c = idx - ww * C;
+            orow[(size_t)ww * R * C + c] = tile[ww * CP + c];
+        }
     }
 }
 
@@ -187,7 +224,7 @@ static int launch_eval_windows(f2_ctx* ctx, const double* d_env, int C, int64_t 
     const int64_t reach = (int64_t)step * radius;
     const int64_t span = n_windows + 2 * reach;
     const int groups = (C + LCH - 1) / LCH;
-    F2_TRY(f2_reserve(ctx, ctx->gather_log, sizeof(double) * ((size_t)span * ((size_t)C + 2 * (size_t)groups) + 3 * (size_t)n_windows)));
+    F2_TRY(f2_reserve(ctx, ctx->gather_log, sizeof(double) * ((size_t)span * ((size_t)C + 2 * (size_t)groups) + 4 * (size_t)n_windows)));
     double* L = (double*)ctx->gather_log.ptr;
     double* pmin = L + (size_t)span * (size_t)C;
     double* pmax = pmin + (size_t)span * (size_t)groups;
