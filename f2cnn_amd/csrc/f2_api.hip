@@ -185,7 +185,7 @@ int f2_ctx_destroy(f2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     f2_scratch* all[] = {&ctx->coefs, &ctx->offsets, &ctx->stage_in, &ctx->stage_out, &ctx->stage_aux,
-                         &ctx->work,  &ctx->work2,   &ctx->xbuf,      &ctx->flags,    &ctx->gather_log};
+                         &ctx->work,  &ctx->work2,   &ctx->xbuf,      &ctx->flags,    &ctx->gather_log, &ctx->dense_in};
     for (f2_scratch* s : all)
         if (s->ptr) (void)hipFree(s->ptr);
     for (auto& v : ctx->prof)

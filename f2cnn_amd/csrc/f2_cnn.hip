@@ -1054,10 +1054,20 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
                   uint8_t* d_labels) {
     if (n <= 0) return F2_OK;
     const Dims d = make_dims(cnn->rows, cnn->channels);
+    float* a4 = d_ws + (size_t)n * d.Hp1 * d.Wp1 * (C2 + C3);
+    F2_TRY(f2_launch_cnn_convs(ctx, cnn, d_x, n, d_ws, a4));
+    return f2_launch_cnn_dense(ctx, cnn, a4, n, a4 + (size_t)n * d.flat, d_scores, d_labels);
+}
+
+size_t f2_cnn_flat_floats(const f2_cnn* cnn) { return (size_t)make_dims(cnn->rows, cnn->channels).flat; }
+size_t f2_cnn_dense_floats(const f2_cnn* cnn) { return (size_t)make_dims(cnn->rows, cnn->channels).flat + D1; }
+
+// conv1 .. conv4 + pools of n windows: d_ws = workspace of (Hp1 Wp1 (C2 + C3)) floats per window, a4 = [n][flat] out
+int f2_launch_cnn_convs(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_ws, float* a4) {
+    if (n <= 0) return F2_OK;
+    const Dims d = make_dims(cnn->rows, cnn->channels);
     float* a2 = d_ws;
     float* a3 = a2 + (size_t)n * d.Hp1 * d.Wp1 * C2;
-    float* a4 = a3 + (size_t)n * d.Hp1 * d.Wp1 * C3;
-    float* a5 = a4 + (size_t)n * d.flat;
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
     const bool ws = ctx->opt_cnn_bf16x3 && ctx->opt_cnn_ws && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels);
     if (ws) {
@@ -1108,6 +1118,17 @@ int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, f
         F2_TRY((launch_conv<C2, C3, true, false, 8, 2>(ctx, a2, cnn->t(4), cnn->t(5), a3, d.Hp1, d.Wp1, n)));
         F2_TRY((launch_conv<C3, C4, false, true, 4, 2>(ctx, a3, cnn->t(6), cnn->t(7), a4, d.Hp1, d.Wp1, n)));
     }
+    F2_TRY(f2_prof_end(ctx, F2_K_CNN));
+    return F2_OK;
+}
+
+// dense1 + dense2 + softmax + labels of n windows from a4 = [n][flat]; a5 = workspace of D1 floats per window. Its workgroups
+// are (64 windows x 6 of the 17 output tiles): launched per 14 240-window utterance that is 669 workgroups for 512 resident
+// ones - a second round one third full - so f2_eval_batch hands it the windows of several utterances at once.
+int f2_launch_cnn_dense(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t n, float* a5, float* d_scores, uint8_t* d_labels) {
+    if (n <= 0) return F2_OK;
+    const Dims d = make_dims(cnn->rows, cnn->channels);
+    F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
     {
         const dim3 grid((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
         constexpr int MT16 = 2;   // (3 - 96 windows, one round of workgroups per 14 240-window chunk - measured slower: 0.165 against 0.157 ms)

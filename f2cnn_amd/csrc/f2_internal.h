@@ -42,6 +42,7 @@ struct f2_ctx {
     f2_scratch work;       // intermediates (GFB between K1 and K2, activations, ...)
     f2_scratch work2;
     f2_scratch xbuf;       // window tensor chunk between K3 and K4
+    f2_scratch dense_in;   // conv4 outputs (+ dense1 outputs) of the windows of several utterances: one dense launch for all
     f2_scratch gather_log; // ln of the envelope samples a chunk of every-sample windows touches + column min / max (f2_gather.hip)
     f2_scratch tw[2][16];  // FFT twiddle tables, [precision][log2 H], built on first use
     f2_scratch tw_fl[16];         // twiddle tables of f2_envelope_flagged.hip, by log2 H
@@ -230,3 +231,8 @@ int f2_launch_cnn_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n
 // runs the network on n windows (n <= chunk the workspace was sized for); d_ws: n * workspace floats
 int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_ws, float* d_scores,
                   uint8_t* d_labels);
+// the two halves of f2_launch_cnn (f2_cnn.hip): convolutions per chunk of windows, dense layers over several chunks at once
+int f2_launch_cnn_convs(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_ws, float* a4);
+int f2_launch_cnn_dense(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t n, float* a5, float* d_scores, uint8_t* d_labels);
+size_t f2_cnn_flat_floats(const f2_cnn* cnn);    // floats per window of the conv4 output
+size_t f2_cnn_dense_floats(const f2_cnn* cnn);   // ... plus dense1's output

@@ -5,6 +5,7 @@
 namespace {
 
 constexpr int64_t CNN_CHUNK = 16384;  // windows per CNN launch group (activation workspace 1.75 GB, windows 92 MB)
+constexpr int64_t DENSE_GROUP = 8 * CNN_CHUNK;   // windows per dense1 / dense2 launch of f2_eval_batch (conv4 + dense1 outputs: 1.3 GB)
 
 int reset_flag(f2_ctx* ctx) {
     F2_HIP(ctx, hipMemsetAsync(ctx->flags.ptr, 0, sizeof(int), ctx->stream));
@@ -249,10 +250,17 @@ int f2_eval_batch(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave_dty
         return F2_OK;
     }
 
-    // every-sample windows -> normalise -> CNN, utterance by utterance, chunk by chunk; nothing leaves HBM
+    // every-sample windows -> normalise -> conv1 .. conv4, utterance by utterance, chunk by chunk; the dense layers run over the
+    // conv4 outputs of up to DENSE_GROUP windows at once (dense1's grid of 64-window workgroups then fills whole rounds of the
+    // device: launched per 14 240-window utterance its second round was one third full); nothing leaves HBM
     const int64_t chunk = nb_max < CNN_CHUNK ? nb_max : CNN_CHUNK;
+    const int64_t group_cap = nb_total < DENSE_GROUP ? nb_total : DENSE_GROUP;
+    const size_t conv_floats = f2_cnn_workspace_floats(cnn) - f2_cnn_dense_floats(cnn), flat = f2_cnn_flat_floats(cnn);
     F2_TRY(f2_reserve(ctx, ctx->xbuf, sizeof(float) * (size_t)chunk * R * (size_t)C));
-    F2_TRY(f2_reserve(ctx, ctx->work, sizeof(float) * f2_cnn_workspace_floats(cnn) * (size_t)chunk));
+    F2_TRY(f2_reserve(ctx, ctx->work, sizeof(float) * conv_floats * (size_t)chunk));
+    F2_TRY(f2_reserve(ctx, ctx->dense_in, sizeof(float) * f2_cnn_dense_floats(cnn) * (size_t)group_cap));
+    float* const d_a4 = (float*)ctx->dense_in.ptr;
+    float* const d_a5 = d_a4 + flat * (size_t)group_cap;
     float* d_scores = scores_or_null;
     uint8_t* d_labels = labels_or_null;
     if (mem_space == F2_MEM_HOST) {
@@ -262,7 +270,14 @@ int f2_eval_batch(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave_dty
     }
     F2_TRY(reset_flag(ctx));
     const int64_t reach = (int64_t)radius * step;
-    int64_t done = 0;
+    int64_t done = 0, g0 = 0, gn = 0;      // windows finished before this utterance; first window and size of the open dense group
+    auto flush = [&]() -> int {
+        if (gn > 0)
+            F2_TRY(f2_launch_cnn_dense(ctx, cnn, d_a4, gn, d_a5, d_scores ? d_scores + 2 * g0 : nullptr, d_labels ? d_labels + g0 : nullptr));
+        g0 += gn;
+        gn = 0;
+        return F2_OK;
+    };
     for (int b = 0; b < B; ++b) {
         const int64_t N = offsets[b + 1] - offsets[b];
         const int64_t nb = N - (int64_t)R * step;
@@ -270,13 +285,15 @@ int f2_eval_batch(f2_ctx* ctx, const f2_cnn* cnn, const void* wave, int wave_dty
         const double* env_b = d_env + (size_t)C * (size_t)offsets[b];
         for (int64_t s = 0; s < nb; s += chunk) {
             const int64_t m = nb - s < chunk ? nb - s : chunk;
+            if (gn + m > group_cap) F2_TRY(flush());
             F2_TRY(f2_launch_gather(ctx, env_b, C, N, nullptr, reach + s, m, radius, step, 1, (float*)ctx->xbuf.ptr,
                                     (int*)ctx->flags.ptr));
-            F2_TRY(f2_launch_cnn(ctx, cnn, (const float*)ctx->xbuf.ptr, m, (float*)ctx->work.ptr,
-                                 d_scores ? d_scores + 2 * (done + s) : nullptr, d_labels ? d_labels + done + s : nullptr));
+            F2_TRY(f2_launch_cnn_convs(ctx, cnn, (const float*)ctx->xbuf.ptr, m, (float*)ctx->work.ptr, d_a4 + flat * (size_t)gn));
+            gn += m;
         }
         done += nb;
     }
+    F2_TRY(flush());
     if (mem_space == F2_MEM_HOST) {
         if (scores_or_null)
             F2_HIP(ctx, hipMemcpyAsync(scores_or_null, d_scores, sizeof(float) * 2 * (size_t)nb_total, hipMemcpyDeviceToHost, ctx->stream));
