@@ -1131,7 +1131,10 @@ int f2_launch_cnn_dense(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
     {
         const dim3 grid((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
-        constexpr int MT16 = 2;   // (3 - 96 windows, one round of workgroups per 14 240-window chunk - measured slower: 0.165 against 0.157 ms)
+#ifndef F2_D1_MT
+#define F2_D1_MT 2
+#endif
+        constexpr int MT16 = F2_D1_MT;   // (3 - 96 windows, one round of workgroups per 14 240-window chunk - measured slower: 0.165 against 0.157 ms)
         const dim3 grid16((unsigned)((n + 32 * MT16 - 1) / (32 * MT16)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
         if (ctx->opt_cnn_bf16x3 && cnn->blob16)
             hipLaunchKernelGGL(k_dense1_bf16x3<MT16>, grid16, dim3(D1_WAVES * 64), 0, ctx->stream, a4,
