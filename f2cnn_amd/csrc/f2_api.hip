@@ -276,6 +276,7 @@ const opt_entry kOptions[] = {
     {"env_plan4", &f2_ctx::opt_env_plan4, nullptr, 0, 1},
     {"cnn_bf16x3", &f2_ctx::opt_cnn_bf16x3, nullptr, 0, 1},
     {"cnn_ws", &f2_ctx::opt_cnn_ws, nullptr, 0, 1},
+    {"cnn_ws_dense", &f2_ctx::opt_cnn_ws_dense, nullptr, 0, 1},
     {"gather_blocked", &f2_ctx::opt_gather_blocked, nullptr, 0, 1},
 };
 const opt_entry* find_option(const char* key) {

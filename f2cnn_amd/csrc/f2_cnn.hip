@@ -1129,7 +1129,10 @@ int f2_launch_cnn_dense(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t
     if (n <= 0) return F2_OK;
     const Dims d = make_dims(cnn->rows, cnn->channels);
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
-    {
+    const bool ws = ctx->opt_cnn_bf16x3 && ctx->opt_cnn_ws && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels);
+    if (ws && ctx->opt_cnn_ws_dense) {
+        F2_TRY(f2_launch_dense1_ws(ctx, cnn, a4, n, d.flat, a5));
+    } else {
         const dim3 grid((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
 #ifndef F2_D1_MT
 #define F2_D1_MT 2

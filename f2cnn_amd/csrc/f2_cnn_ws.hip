@@ -32,6 +32,8 @@
 //
 // Layout of an MFMA operand (tools/ubench/mfma_bf16_layout.hip): lane (i, h) supplies k = 8 h .. 8 h + 7 of row / column i;
 // accumulator register q of lane (i, h) is row (q & 3) + 8 (q >> 2) + 4 h, column i.
+#include <type_traits>
+
 #include "f2_internal.h"
 
 namespace {
@@ -702,6 +704,171 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// dense1 from pre-split activations
+// ------------------------------------------------------------------------------------------------------------------
+// out (n, D1) = ReLU(a (n, K) W (K, D1) + b). k_dense1_bf16x3 (f2_cnn.hip) streams 2 KB of split weights per wave and K step for 6
+// MFMAs (64 windows per workgroup) and lets the compiler place the waits of its prefetched loads: vmcnt(0) at the head of every
+// chunk, the fragment requested a moment ago included. Here a weight fragment feeds 3 MT MFMAs (MT = 3: 96 windows), every
+// global load of the K loop is issued and waited for by hand (two K steps ahead for the weights, a chunk ahead for the
+// activations), and the activations' hi / lo chunks sit XOR-swizzled in LDS so that ds_read_b128 of 32 consecutive rows is
+// conflict-free (chunk c of row r at r * 128 + ((c ^ (r & 7)) << 4)). 6 waves = 6 output tiles per workgroup, two workgroups
+// per CU. (conv4 leaving its outputs already split - two 2-byte stores or one packed dword per value - was measured too: it
+// takes 18 us out of this kernel's staging and puts them into k_conv34_ws's combine, which runs beside matrix loops.)
+constexpr int D1W_WAVES = 6, D1W_KC = 64, D1W_TILES = 17, D1W_NPAD = D1W_TILES * 32, D1W_N = 516;
+template <int MT>
+__global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __restrict__ a, const bf16x8* __restrict__ ws,
+                                                                 const float* __restrict__ bias, float* __restrict__ out, int K,
+                                                                 int64_t n) {
+    constexpr int ROWS = 32 * MT, PIECE = ROWS * 128, BUF = 2 * PIECE;
+    static_assert(2 * BUF <= 80 * 1024 && 2 * BUF - 1 + 0 < 65536, "two workgroups per CU; immediate ds offsets");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t w0 = (int64_t)blockIdx.x * ROWS;
+    const int nchunks = K / D1W_KC, nsteps = nchunks * 4;
+    const int nt = blockIdx.y * D1W_WAVES + wave;
+    const bool live = nt < D1W_TILES;
+    const int ntc = live ? nt : D1W_TILES - 1;                       // (idle waves load a valid tile and discard it)
+    const bf16x8* wh = ws + (int64_t)h * D1W_NPAD + ntc * 32 + i;    // w[piece][chunk][ks][h][n (544)][8]
+    const bf16x8* wl = wh + (int64_t)nchunks * 4 * 2 * D1W_NPAD;
+
+    // Staging: thread slot s = tid + 384 m = (row, chunk c of eight K values): two 16-byte loads (eight float32), split, two
+    // 16-byte LDS stores (hi and lo chunk) at position c ^ (row & 7) of the row in either piece; rows
+    // past n read row n - 1 (their results are not stored). Through registers rather than by LDS-DMA: vmcnt counts in order, so a
+    // wait for a weight fragment also waits for everything issued before it - either way two K steps after its issue.
+    constexpr int NPAIR = ROWS * 8, PERT = (NPAIR + D1W_WAVES * 64 - 1) / (D1W_WAVES * 64);
+    unsigned srcoff[PERT];
+    int dstoff[PERT];
+#pragma unroll
+    for (int m = 0; m < PERT; ++m) {
+        const int sl = min((int)threadIdx.x + D1W_WAVES * 64 * m, NPAIR - 1);
+        const int row = sl >> 3, c = sl & 7;
+        const int64_t wr = w0 + row < n ? w0 + row : n - 1;
+        srcoff[m] = (unsigned)(wr * (int64_t)K + c * 8) * 4u;                    // bytes (n x K dwords < 4 GB: f2_launch_dense1_ws checks)
+        dstoff[m] = (int)threadIdx.x + D1W_WAVES * 64 * m < NPAIR ? row * 128 + ((c ^ (row & 7)) << 4) : -1;
+    }
+    // Every global load of the K loop is issued through inline asm and waited for by hand: left to the compiler, the waits at the
+    // head of the loop come out as vmcnt(0) - the fragment requested a moment ago included (a full L2 latency per chunk).
+    // vmcnt counts in order: a wait for N = everything but the N youngest loads has arrived.
+    u32x4 ar[2 * PERT];
+    auto gload = [](u32x4& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory"); };
+    auto load_a = [&](int kc) {
+#pragma unroll
+        for (int m = 0; m < PERT; ++m) {
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(a) + srcoff[m] + kc * (D1W_KC * 4);
+            gload(ar[2 * m], p);
+            gload(ar[2 * m + 1], p + 16);
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int m = 0; m < PERT; ++m) {
+            const f32x4 x = __builtin_bit_cast(f32x4, ar[2 * m]), y = __builtin_bit_cast(f32x4, ar[2 * m + 1]);
+            bf16x4 h0, l0, h1, l1;
+            split4(x[0], x[1], x[2], x[3], h0, l0);
+            split4(y[0], y[1], y[2], y[3], h1, l1);
+            if (dstoff[m] >= 0) {
+                *reinterpret_cast<bf16x8*>(lds + buf * BUF + dstoff[m]) = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                *reinterpret_cast<bf16x8*>(lds + buf * BUF + PIECE + dstoff[m]) = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            }
+        }
+    };
+    // this lane's 16 bytes of K step ks in row i of an M tile: + 4096 t + PIECE piece + BUF buffer (immediates)
+    int aoff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) aoff[ks] = i * 128 + (((2 * ks + h) ^ (i & 7)) << 4);
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    // weight fragments: a ring of four K steps (slot = ks, compile-time), requested two steps ahead
+    u32x4 bh[4], bl[4];
+    auto load_b = [&](int step, int slot) {
+        gload(bh[slot], wh + (int64_t)step * 2 * D1W_NPAD);
+        gload(bl[slot], wl + (int64_t)step * 2 * D1W_NPAD);
+    };
+    // (the fragment is an operand of the wait, so that its MFMAs cannot be scheduled ahead of it)
+#define D1W_WAIT(N, slot) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bh[slot]), "+v"(bl[slot])::"memory")
+    auto step_mfmas = [&](const unsigned char* pa, int ks) {
+        // activations one M tile ahead of the MFMAs that use them
+        const bf16x8 wb_h = __builtin_bit_cast(bf16x8, bh[ks]), wb_l = __builtin_bit_cast(bf16x8, bl[ks]);
+        bf16x8 ah[2], al[2];
+        ah[0] = *reinterpret_cast<const bf16x8*>(pa + aoff[ks]);
+        al[0] = *reinterpret_cast<const bf16x8*>(pa + aoff[ks] + PIECE);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            if (t + 1 < MT) {
+                ah[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(pa + aoff[ks] + (t + 1) * 4096);
+                al[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(pa + aoff[ks] + (t + 1) * 4096 + PIECE);
+            }
+            acc[t] = MFMA16(al[t & 1], wb_h, acc[t]);
+            acc[t] = MFMA16(ah[t & 1], wb_l, acc[t]);
+            acc[t] = MFMA16(ah[t & 1], wb_h, acc[t]);
+        }
+    };
+    load_a(0);
+    load_b(0, 0);
+    load_b(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ar[0]), "+v"(ar[2 * PERT - 1])::"memory");
+#pragma unroll
+    for (int m = 1; m + 1 < 2 * PERT; ++m) asm volatile("" : "+v"(ar[m]));
+    store_a(0);
+    __syncthreads();
+    constexpr int NA = 2 * PERT + 4;                                 // loads younger than the fragment of steps 0 / 1 of a chunk
+    int kc = 0;
+    for (; kc + 1 < nchunks; ++kc) {
+        // issue order of a chunk: activations of chunk kc + 1, then the weight fragments of steps +2: L2, L3, L0', L1'
+        load_a(kc + 1);
+        const unsigned char* pa = lds + (kc & 1) * BUF;
+        load_b(kc * 4 + 2, 2);
+        if constexpr (NA == 10) D1W_WAIT(10, 0); else if constexpr (NA == 9) D1W_WAIT(9, 0); else if constexpr (NA == 8) D1W_WAIT(8, 0); else D1W_WAIT(0, 0);
+        step_mfmas(pa, 0);
+        load_b(kc * 4 + 3, 3);
+        if constexpr (NA == 10) D1W_WAIT(10, 1); else if constexpr (NA == 9) D1W_WAIT(9, 1); else if constexpr (NA == 8) D1W_WAIT(8, 1); else D1W_WAIT(0, 1);
+        step_mfmas(pa, 1);
+        load_b(kc * 4 + 4, 0);
+        D1W_WAIT(4, 2);                                              // (the activations, older than fragment 2, have arrived as well)
+        step_mfmas(pa, 2);
+        load_b(kc * 4 + 5, 1);
+        D1W_WAIT(4, 3);
+#pragma unroll
+        for (int m = 0; m < 2 * PERT; ++m) asm volatile("" : "+v"(ar[m]));
+        step_mfmas(pa, 3);
+        store_a((kc + 1) & 1);                                       // (that buffer was read in chunk kc - 1: behind that chunk's barrier)
+        __syncthreads();
+    }
+    {
+        // last chunk: fragments 0, 1 are in flight, 2 and 3 still to request
+        const unsigned char* pa = lds + (kc & 1) * BUF;
+        load_b(kc * 4 + 2, 2);
+        load_b(kc * 4 + 3, 3);
+        D1W_WAIT(4, 0);
+        step_mfmas(pa, 0);
+        D1W_WAIT(4, 1);
+        step_mfmas(pa, 1);
+        D1W_WAIT(0, 2);
+        step_mfmas(pa, 2);
+        D1W_WAIT(0, 3);
+        step_mfmas(pa, 3);
+    }
+#undef D1W_WAIT
+    const int col = nt * 32 + i;
+    if (live && col < D1W_N) {
+        float b = bias[col];
+        asm volatile("" : "+v"(b));        // (settled here: see k_conv12_ws)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t wr = w0 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (wr < n) out[wr * D1W_N + col] = relu(acc[t][q] + b);
+            }
+    }
+}
+
 }  // namespace
 
 // conv1 .. conv4 + pools of n windows: x (n, H1, W1) float32 -> a2s (n, 4, W1/2 - 1, [hi 32 | lo 32]) bf16 (scratch) ->
@@ -791,5 +958,22 @@ int f2_launch_cnn_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n
         ws_stamp_report(ctx, "k_conv34_ws (waves 0-3 conv3; 4-7 conv4: slot4 = K halves combined + stored, slot5 = LDS-DMA issued)", d_stamps);
 #endif
     }
+    return F2_OK;
+}
+
+// dense1 of n windows: a4 (n, K) float32 -> a5 (n, 516) float32
+int f2_launch_dense1_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t n, int K, float* a5) {
+    F2_CHECK(ctx, K % D1W_KC == 0 && K >= 2 * D1W_KC && n * (int64_t)K * 4 < (int64_t(1) << 32), F2_ERR_UNSUPPORTED,
+             "dense1: %lld windows x %d inputs", (long long)n, K);
+#ifndef F2_D1W_MT
+#define F2_D1W_MT 3
+#endif
+    constexpr int MT = F2_D1W_MT;
+    constexpr int LDSB = 2 * 2 * 32 * MT * 128;
+    F2_HIP(ctx, hipFuncSetAttribute((const void*)k_dense1_ws<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    const dim3 grid((unsigned)((n + 32 * MT - 1) / (32 * MT)), (D1W_TILES + D1W_WAVES - 1) / D1W_WAVES);
+    hipLaunchKernelGGL(k_dense1_ws<MT>, grid, dim3(D1W_WAVES * 64), LDSB, ctx->stream, a4,
+                       (const bf16x8*)(cnn->blob16 + cnn->off16[3]), cnn->t(9), a5, K, n);
+    F2_HIP(ctx, hipGetLastError());
     return F2_OK;
 }

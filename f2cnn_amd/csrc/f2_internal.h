@@ -89,6 +89,7 @@ struct f2_ctx {
     int opt_env_pair = 1;                 // on-chip kernel for rows of 32769..65536 samples
     int opt_cnn_bf16x3 = 1;               // conv3 + conv4 on the bf16 matrix cores, operands split in two pieces (3 MFMAs per product)
     int opt_cnn_ws = 1;                   // ... with the weights of each wave's role held in registers (f2_cnn_ws.hip; windows of 10 / 11 rows)
+    int opt_cnn_ws_dense = 1;             // ... and dense1 with 96 windows per weight fragment, loads waited for by hand (k_dense1_ws)
     int opt_gather_blocked = 1;           // every-sample windows: logarithm once per sample, blocks of 32 windows (0: one workgroup per window)
     int opt_env_plan4 = 0;                // four-pass plan for every 1 s row (default: three passes where measured faster)
     // pinned staging of small host -> device uploads (f2_upload_async): a ring of page-locked memory the copies read from,
@@ -227,6 +228,7 @@ int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const i
                      int64_t first_center, int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag);
 // weight-stationary split-bf16 convolutions (f2_cnn_ws.hip): windows whose pooled conv2 output has four rows
 bool f2_cnn_ws_supported(int rows, int channels);
+int f2_launch_dense1_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t n, int K, float* a5);
 int f2_launch_cnn_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, void* a2s, float* a4);
 // runs the network on n windows (n <= chunk the workspace was sized for); d_ws: n * workspace floats
 int f2_launch_cnn(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n, float* d_ws, float* d_scores,

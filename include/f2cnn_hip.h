@@ -88,6 +88,8 @@ const char* f2_last_error(f2_ctx* ctx);
  *   "cnn_ws"         1 (default) / 0   with "cnn_bf16x3", windows of 10 / 11 rows (the reference's 11 x C): persistent weight-
  *                                      stationary kernels (each wave keeps the weights of its role in registers, conv1 on the
  *                                      matrix cores too, one barrier per tile); 0 = one workgroup per tile, weights re-read
+ *   "cnn_ws_dense"   1 (default) / 0   with "cnn_ws": dense1 on 96-window tiles (a weight fragment feeds nine MFMAs), its loads
+ *                                      issued and waited for by hand; 0 = the 64-window kernel of "cnn_bf16x3"
  *   "gather_blocked" 1 (default) / 0   every-sample normalised windows (f2_gather_windows without centres, f2_eval_*): logarithm
  *                                      once per envelope sample and blocks of 32 consecutive windows, bit-identical to 0 = one
  *                                      workgroup per window
