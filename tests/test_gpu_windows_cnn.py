@@ -130,16 +130,19 @@ def test_cnn_f32_and_split_bf16_matrix_paths(rows, channels):
     assert ctx.get_option("cnn_bf16x3") == 1 and ctx.get_option("cnn_ws") == 1
     got = {}
     try:
-        for name, bf, ws in (("f32", 0, 0), ("bf16x3", 1, 0), ("ws", 1, 1)):
+        # (ws64: the weight-stationary convolutions with the 64-window dense1 kernel of the split path instead of k_dense1_ws)
+        for name, bf, ws, wsd in (("f32", 0, 0, 1), ("bf16x3", 1, 0, 1), ("ws", 1, 1, 1), ("ws64", 1, 1, 0)):
             ctx.set_option("cnn_bf16x3", bf)
             ctx.set_option("cnn_ws", ws)
+            ctx.set_option("cnn_ws_dense", wsd)
             got[name] = m.predict(x, ctx)
             np.testing.assert_allclose(got[name], ref, atol=2e-5, err_msg=name)
     finally:
         ctx.set_option("cnn_bf16x3", 1)
         ctx.set_option("cnn_ws", 1)
+        ctx.set_option("cnn_ws_dense", 1)
     clear = np.abs(ref[:, 1] - ref[:, 0]) > 1e-5
-    for name in ("bf16x3", "ws"):
+    for name in ("bf16x3", "ws", "ws64"):
         assert np.abs(got[name] - got["f32"]).max() <= 2e-6, name
         assert not np.array_equal(got[name], got["f32"]), name        # (the option is not a no-op)
         np.testing.assert_array_equal((got[name][:, 1] > got[name][:, 0])[clear], (got["f32"][:, 1] > got["f32"][:, 0])[clear])
