@@ -784,7 +784,7 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-    // weight fragments: a ring of four K steps (slot = ks, compile-time), requested two steps ahead
+    // weight fragments: a ring of four K steps (slot = ks, compile-time)
     u32x4 bh[4], bl[4];
     auto load_b = [&](int step, int slot) {
         gload(bh[slot], wh + (int64_t)step * 2 * D1W_NPAD);
@@ -809,31 +809,41 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
             acc[t] = MFMA16(ah[t & 1], wb_h, acc[t]);
         }
     };
+    // Fragments are requested THREE steps ahead (the ring's fourth slot is the one the previous step has just consumed). Issue
+    // order of a chunk: activations of chunk kc + 1 (2 PERT loads), then per step one fragment pair; a wait for the fragment
+    // of steps 0 - 2 leaves the NA = 2 PERT + 6 younger loads in flight, step 3's the six of the three pairs behind it -
+    // which also means the activations, older than that fragment, have arrived.
     load_a(0);
     load_b(0, 0);
     load_b(1, 1);
+    load_b(2, 2);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ar[0]), "+v"(ar[2 * PERT - 1])::"memory");
 #pragma unroll
     for (int m = 1; m + 1 < 2 * PERT; ++m) asm volatile("" : "+v"(ar[m]));
     store_a(0);
     __syncthreads();
-    constexpr int NA = 2 * PERT + 4;                                 // loads younger than the fragment of steps 0 / 1 of a chunk
+    constexpr int NA = 2 * PERT + 6;
+    static_assert(NA == 10 || NA == 12, "MT = 3 or 4");
+#define D1W_WAIT_NA(slot)                      \
+    do {                                       \
+        if constexpr (NA == 10) D1W_WAIT(10, slot); \
+        else D1W_WAIT(12, slot);               \
+    } while (0)
     int kc = 0;
     for (; kc + 1 < nchunks; ++kc) {
-        // issue order of a chunk: activations of chunk kc + 1, then the weight fragments of steps +2: L2, L3, L0', L1'
         load_a(kc + 1);
         const unsigned char* pa = lds + (kc & 1) * BUF;
-        load_b(kc * 4 + 2, 2);
-        if constexpr (NA == 10) D1W_WAIT(10, 0); else if constexpr (NA == 9) D1W_WAIT(9, 0); else if constexpr (NA == 8) D1W_WAIT(8, 0); else D1W_WAIT(0, 0);
-        step_mfmas(pa, 0);
         load_b(kc * 4 + 3, 3);
-        if constexpr (NA == 10) D1W_WAIT(10, 1); else if constexpr (NA == 9) D1W_WAIT(9, 1); else if constexpr (NA == 8) D1W_WAIT(8, 1); else D1W_WAIT(0, 1);
-        step_mfmas(pa, 1);
+        D1W_WAIT_NA(0);
+        step_mfmas(pa, 0);
         load_b(kc * 4 + 4, 0);
-        D1W_WAIT(4, 2);                                              // (the activations, older than fragment 2, have arrived as well)
-        step_mfmas(pa, 2);
+        D1W_WAIT_NA(1);
+        step_mfmas(pa, 1);
         load_b(kc * 4 + 5, 1);
-        D1W_WAIT(4, 3);
+        D1W_WAIT_NA(2);
+        step_mfmas(pa, 2);
+        load_b(kc * 4 + 6, 2);
+        D1W_WAIT(6, 3);
 #pragma unroll
         for (int m = 0; m < 2 * PERT; ++m) asm volatile("" : "+v"(ar[m]));
         step_mfmas(pa, 3);
@@ -841,19 +851,19 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
         __syncthreads();
     }
     {
-        // last chunk: fragments 0, 1 are in flight, 2 and 3 still to request
+        // last chunk: fragments 0 - 2 are in flight, 3 still to request
         const unsigned char* pa = lds + (kc & 1) * BUF;
-        load_b(kc * 4 + 2, 2);
         load_b(kc * 4 + 3, 3);
-        D1W_WAIT(4, 0);
+        D1W_WAIT(6, 0);
         step_mfmas(pa, 0);
         D1W_WAIT(4, 1);
         step_mfmas(pa, 1);
-        D1W_WAIT(0, 2);
+        D1W_WAIT(2, 2);
         step_mfmas(pa, 2);
         D1W_WAIT(0, 3);
         step_mfmas(pa, 3);
     }
+#undef D1W_WAIT_NA
 #undef D1W_WAIT
     const int col = nt * 32 + i;
     if (live && col < D1W_N) {
