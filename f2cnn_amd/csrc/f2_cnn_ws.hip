@@ -712,7 +712,8 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
 // chunk, the fragment requested a moment ago included. Here a weight fragment feeds 3 MT MFMAs (MT = 3: 96 windows), every
 // global load of the K loop is issued and waited for by hand (two K steps ahead for the weights, a chunk ahead for the
 // activations), and the activations' hi / lo chunks sit XOR-swizzled in LDS so that ds_read_b128 of 32 consecutive rows is
-// conflict-free (chunk c of row r at r * 128 + ((c ^ (r & 7)) << 4)). 6 waves = 6 output tiles per workgroup, two workgroups
+// conflict-free (chunk c of row r at r * 128 + ((c ^ ((r >> 1) & 7)) << 4): a 16-lane group of the read covers eight even and eight
+// odd rows, whose halves of the 256-byte bank window are fixed by the row's parity). 6 waves = 6 output tiles per workgroup, two workgroups
 // per CU. (conv4 leaving its outputs already split - two 2-byte stores or one packed dword per value - was measured too: it
 // takes 18 us out of this kernel's staging and puts them into k_conv34_ws's combine, which runs beside matrix loops.)
 constexpr int D1W_WAVES = 6, D1W_KC = 64, D1W_TILES = 17, D1W_NPAD = D1W_TILES * 32, D1W_N = 516;
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
     const bf16x8* wl = wh + (int64_t)nchunks * 4 * 2 * D1W_NPAD;
 
     // Staging: thread slot s = tid + 384 m = (row, chunk c of eight K values): two 16-byte loads (eight float32), split, two
-    // 16-byte LDS stores (hi and lo chunk) at position c ^ (row & 7) of the row in either piece; rows
+    // 16-byte LDS stores (hi and lo chunk) at position c ^ ((row >> 1) & 7) of the row in either piece; rows
     // past n read row n - 1 (their results are not stored). Through registers rather than by LDS-DMA: vmcnt counts in order, so a
     // wait for a weight fragment also waits for everything issued before it - either way two K steps after its issue.
     constexpr int NPAIR = ROWS * 8, PERT = (NPAIR + D1W_WAVES * 64 - 1) / (D1W_WAVES * 64);
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
         const int row = sl >> 3, c = sl & 7;
         const int64_t wr = w0 + row < n ? w0 + row : n - 1;
         srcoff[m] = (unsigned)(wr * (int64_t)K + c * 8) * 4u;                    // bytes (n x K dwords < 4 GB: f2_launch_dense1_ws checks)
-        dstoff[m] = (int)threadIdx.x + D1W_WAVES * 64 * m < NPAIR ? row * 128 + ((c ^ (row & 7)) << 4) : -1;
+        dstoff[m] = (int)threadIdx.x + D1W_WAVES * 64 * m < NPAIR ? row * 128 + ((c ^ ((row >> 1) & 7)) << 4) : -1;
     }
     // Every global load of the K loop is issued through inline asm and waited for by hand: left to the compiler, the waits at the
     // head of the loop come out as vmcnt(0) - the fragment requested a moment ago included (a full L2 latency per chunk).
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
     // this lane's 16 bytes of K step ks in row i of an M tile: + 4096 t + PIECE piece + BUF buffer (immediates)
     int aoff[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) aoff[ks] = i * 128 + (((2 * ks + h) ^ (i & 7)) << 4);
+    for (int ks = 0; ks < 4; ++ks) aoff[ks] = i * 128 + (((2 * ks + h) ^ ((i >> 1) & 7)) << 4);
 
     f32x16 acc[MT];
 #pragma unroll

@@ -21,7 +21,7 @@ times = {}
 for r in csv.DictReader(open(sys.argv[2])):
     times[r["Name"]] = float(r["AverageNs"]) * 1e-9
 for key, p in pmc.items():
-    name = next((n for n in ("k_conv12_ws", "k_conv34_ws", "k_dense1_bf16x3", "k_conv12_bf16x3", "k_conv34_bf16x3") if n in key), None)
+    name = next((n for n in ("k_conv12_ws", "k_conv34_ws", "k_dense1_ws", "k_dense1_bf16x3", "k_conv12_bf16x3", "k_conv34_bf16x3") if n in key), None)
     if not name or "SQ_INSTS_MFMA" not in p:
         continue
     t = next((v for k, v in times.items() if name in k), None)
@@ -34,7 +34,7 @@ for key, p in pmc.items():
     print(f"{name}: {t * 1e3:.3f} ms per 14 240 windows at {clock / 1e9:.2f} GHz (profiler)")
     print(f"   matrix cores busy {busy * 1e3:.3f} ms = {busy / t:.2f} of the kernel ({mfma / 1e6:.2f} M MFMAs, 32 cycles each per SIMD)")
     print(f"   per MFMA: {valu / mfma:.2f} VALU, {p['SQ_INSTS_SALU'] / mfma:.2f} scalar, {p['SQ_INSTS_LDS'] / mfma:.2f} LDS instructions "
-          f"({p.get('SQ_INSTS_VALU_CVT', 0) / mfma:.2f} of the VALU are conversions)")
+          f"({p.get('SQ_INSTS_VALU_CVT', 0) / mfma:.2f} conversions per MFMA among the VALU)")
     lds = p["SQ_LDS_IDX_ACTIVE"] / CUS / clock
     print(f"   LDS array {lds * 1e3:.3f} ms = {lds / t:.2f} of the kernel, {p['SQ_LDS_BANK_CONFLICT'] / p['SQ_LDS_IDX_ACTIVE']:.2f} of it bank conflicts")
     print(f"   wave time: {100 * p['SQ_ACTIVE_INST_ANY'] / waves:.0f} % issuing, {100 * p['SQ_WAIT_INST_ANY'] / waves:.0f} % stalled at issue "
