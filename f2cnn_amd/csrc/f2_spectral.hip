@@ -962,6 +962,53 @@ __global__ __launch_bounds__((64 * TAIL_WAVES)) void k_tail_state(const WaveT* _
 
 // samples after which n^3 r^n stays below tol x its peak (r = pole radius); 0 if the poles are not a complex pair
 // inside the unit circle or the answer exceeds `limit`
+// ---- the tables of a (coefficient table, length class), built on the device ----
+// Row c < C: HU[c][q] = {Hs.re, Hs.im, u.re, u.im}, q = 0 .. H, u = 1 / D(w_q), Hs = (2 / M) s N_1 .. N_4 u^4 (float64 arithmetic,
+// float32 out; entries H + 1 .. tpitch - 1 zero); row C: E[q] = w_q = exp(-2 pi i q / M), q < M (and its float64 copy for
+// k_spectrum_combine). On eight host threads this took 29 / 51 / 93 ms of the first call of a length class (1 / 2 / 4 s rows,
+// 128 channels): a one-shot `prepare envelope` over a few hundred files spent a third of its time there.
+__global__ __launch_bounds__(256) void k_spectral_tables(const double* __restrict__ coefs, int C, int H, int64_t tpitch,
+                                                         f2_f4* __restrict__ hu, cpx<float>* __restrict__ e,
+                                                         cpx<double>* __restrict__ e64) {
+    const int M = 2 * H;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    double sn, cs;
+    sincospi(2.0 * (double)q / (double)M, &sn, &cs);
+    const double wr = cs, wi = -sn;
+    if (c == C) {
+        if (q < M) {
+            e[q] = {(float)wr, (float)wi};
+            if (e64) e64[q] = {wr, wi};
+        }
+        return;
+    }
+    if (q >= tpitch) return;
+    f2_f4 out = {0.f, 0.f, 0.f, 0.f};
+    if (q <= H) {
+        const double* k = coefs + (size_t)c * 10;
+        const double rB0 = 1.0 / k[6];
+        const double b0 = k[0] * rB0, a1 = k[7] * rB0, a2 = k[8] * rB0;
+        const double s = (b0 * b0) * (b0 * b0) / k[9] * (2.0 / M);
+        const double w2r = wr * wr - wi * wi, w2i = 2.0 * wr * wi;
+        const double dr = 1.0 + a1 * wr + a2 * w2r, di = a1 * wi + a2 * w2i;
+        const double dn = 1.0 / (dr * dr + di * di);
+        const double ur = dr * dn, ui = -di * dn;
+        double hr = s, hi = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const double cm = k[1 + m] / k[0];
+            const double nr = 1.0 + cm * wr, ni = cm * wi;
+            const double tr = nr * ur - ni * ui, ti = nr * ui + ni * ur;      // N_m u
+            const double xr = hr * tr - hi * ti, xi = hr * ti + hi * tr;
+            hr = xr;
+            hi = xi;
+        }
+        out = {(float)hr, (float)hi, (float)ur, (float)ui};
+    }
+    hu[(size_t)c * tpitch + q] = out;
+}
+
 int64_t ringing_length(double a1, double a2, double tol, int64_t limit) {
     if (!(a2 > 1e-3 && a2 < 1.0) || a1 * a1 >= 4.0 * a2) return 0;
     const double lr = 0.5 * std::log(a2);   // log r < 0
@@ -1006,7 +1053,7 @@ bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::ve
     return true;
 }
 
-static int spectral_tables(f2_ctx* ctx, int C, int log2h, f2_spec_tables** out) {
+static int spectral_tables(f2_ctx* ctx, const double* d_coefs, int C, int log2h, f2_spec_tables** out) {
     for (auto& t : ctx->spec_tabs)
         if (t.log2h == log2h && t.C == C && t.coefs == ctx->coefs_host) {
             *out = &t;
@@ -1027,58 +1074,13 @@ static int spectral_tables(f2_ctx* ctx, int C, int log2h, f2_spec_tables** out) 
     if (!f2_spectral_supports_coefs(t.coefs, C, &Lg)) return f2_fail(ctx, F2_ERR_INVALID, "coefficient table not eligible");
     const int H = 1 << log2h, M = 2 * H;
     t.tpitch = H + 8;
-    typedef std::complex<double> cd;
-    std::vector<cd> w((size_t)M);
-    std::vector<float> e((size_t)M * 2);
-    std::vector<double> e64((size_t)(log2h > 13 ? M : 0) * 2);   // float64 copy for k_spectrum_combine (decimated utterances)
-    const long double tau = 2.0L * 3.14159265358979323846264338327950288L;
-    for (int q = 0; q < M; ++q) {
-        const long double ang = tau * (long double)q / (long double)M;
-        w[(size_t)q] = cd((double)cosl(ang), (double)(-sinl(ang)));
-        e[2 * (size_t)q] = (float)cosl(ang);
-        e[2 * (size_t)q + 1] = (float)(-sinl(ang));
-        if (!e64.empty()) {
-            e64[2 * (size_t)q] = (double)cosl(ang);
-            e64[2 * (size_t)q + 1] = (double)(-sinl(ang));
-        }
-    }
-    std::vector<float> hu((size_t)C * t.tpitch * 4, 0.f);
-    auto work = [&](int cbeg, int cend) {
-        for (int c = cbeg; c < cend; ++c) {
-            const double* k = &t.coefs[(size_t)c * 10];
-            const double rB0 = 1.0 / k[6];
-            const double b0 = k[0] * rB0, a1 = k[7] * rB0, a2 = k[8] * rB0;
-            const double cm[4] = {k[1] / k[0], k[2] / k[0], k[3] / k[0], k[4] / k[0]};
-            const double s = (b0 * b0) * (b0 * b0) / k[9] * (2.0 / M);
-            float* row = &hu[(size_t)c * t.tpitch * 4];
-            for (int q = 0; q <= H; ++q) {
-                const cd wq = w[(size_t)q];
-                const cd u = 1.0 / (1.0 + a1 * wq + a2 * wq * wq);
-                cd h = s;
-                for (int m = 0; m < 4; ++m) h *= (1.0 + cm[m] * wq) * u;
-                row[4 * (size_t)q] = (float)h.real();
-                row[4 * (size_t)q + 1] = (float)h.imag();
-                row[4 * (size_t)q + 2] = (float)u.real();
-                row[4 * (size_t)q + 3] = (float)u.imag();
-            }
-        }
-    };
-    {
-        const int nth = std::max(1, std::min(8, C / 8));
-        std::vector<std::thread> th;
-        for (int i = 0; i < nth; ++i) th.emplace_back(work, C * i / nth, C * (i + 1) / nth);
-        for (auto& x : th) x.join();
-    }
-    F2_TRY(f2_reserve(ctx, t.hu, sizeof(float) * hu.size()));
-    F2_TRY(f2_reserve(ctx, t.e, sizeof(float) * e.size()));
+    F2_TRY(f2_reserve(ctx, t.hu, sizeof(float) * 4 * (size_t)C * (size_t)t.tpitch));
+    F2_TRY(f2_reserve(ctx, t.e, sizeof(float) * 2 * (size_t)M));
     F2_TRY(f2_reserve(ctx, t.lgroup, sizeof(int) * Lg.size()));
-    if (!e64.empty()) {
-        F2_TRY(f2_reserve(ctx, t.e64, sizeof(double) * e64.size()));
-        F2_TRY(f2_upload_async(ctx, t.e64.ptr, e64.data(), sizeof(double) * e64.size()));
-    }
-    // (the sources are locals: staged through page-locked memory, one-off buffers for the large tables)
-    F2_TRY(f2_upload_async(ctx, t.hu.ptr, hu.data(), sizeof(float) * hu.size()));
-    F2_TRY(f2_upload_async(ctx, t.e.ptr, e.data(), sizeof(float) * e.size()));
+    if (log2h > 13) F2_TRY(f2_reserve(ctx, t.e64, sizeof(double) * 2 * (size_t)M));   // float64 copy for k_spectrum_combine (decimated utterances)
+    hipLaunchKernelGGL(k_spectral_tables, dim3((unsigned)((M + 255) / 256), (unsigned)(C + 1)), dim3(256), 0, ctx->stream, d_coefs, C, H,
+                       t.tpitch, (f2_f4*)t.hu.ptr, (cpx<float>*)t.e.ptr, (cpx<double>*)t.e64.ptr);
+    F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_upload_async(ctx, t.lgroup.ptr, Lg.data(), sizeof(int) * Lg.size()));
     ctx->spec_tabs.push_back(std::move(t));
     *out = &ctx->spec_tabs.back();
@@ -1122,7 +1124,7 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
                         cpx<float>* d_X, float* d_rho) {
     constexpr int H = 1 << LOG2H, M = 2 * H;
     f2_spec_tables* tab = nullptr;
-    F2_TRY(spectral_tables(ctx, C, LOG2H, &tab));
+    F2_TRY(spectral_tables(ctx, d_coefs, C, LOG2H, &tab));
     // float64 transform of the utterances: 2^13 packed complex points fit in LDS; longer rows are decimated in time
     constexpr int LOGD = LOG2H > 13 ? LOG2H - 13 : 0, LOG2HS = LOG2H - LOGD;
     constexpr int FFTLOG = LOG2H == 15 ? 14 : LOG2H;   // rows of the longest class: four 16384-point transforms each
