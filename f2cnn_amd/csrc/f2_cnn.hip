@@ -1130,7 +1130,7 @@ int f2_launch_cnn_dense(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t
     const Dims d = make_dims(cnn->rows, cnn->channels);
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
     const bool ws = ctx->opt_cnn_bf16x3 && ctx->opt_cnn_ws && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels);
-    if (ws && ctx->opt_cnn_ws_dense) {
+    if (ws && ctx->opt_cnn_ws_dense && d.flat % 64 == 0 && d.flat >= 128 && n * (int64_t)d.flat * 4 < (int64_t(1) << 32)) {
         F2_TRY(f2_launch_dense1_ws(ctx, cnn, a4, n, d.flat, a5));
     } else {
         const dim3 grid((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
