@@ -30,6 +30,9 @@
 //                 accumulator rows = output channels as above); waves 4-7: the two K halves of tile t - 1 meet (first half: sum,
 //                 pool, bias, store), then conv4 (output tile nt, K half) of tile t from patch B.
 //
+//   k_dense1_ws   96 windows x 6 output tiles per 6-wave workgroup (two per CU), weights streamed two 16-byte loads per lane
+//                 and K step into a ring, activations split on their way into LDS; every load of the K loop waited for by hand.
+//
 // Layout of an MFMA operand (tools/ubench/mfma_bf16_layout.hip): lane (i, h) supplies k = 8 h .. 8 h + 7 of row / column i;
 // accumulator register q of lane (i, h) is row (q & 3) + 8 (q >> 2) + 4 h, column i.
 #include <type_traits>
