@@ -150,6 +150,27 @@ def test_cnn_f32_and_split_bf16_matrix_paths(rows, channels):
         assert not np.array_equal(got["ws"], got["bf16x3"])           # the weight-stationary kernels ran (conv1 differs)
 
 
+@pytest.mark.parametrize("rows,channels", [(11, 128), (10, 100)])
+def test_cnn_weight_stationary_kernels_at_awkward_window_counts(rows, channels):
+    """The persistent kernels walk (window, column tile) tasks with a stride of the grid and dense1 takes 96 windows per workgroup:
+    window counts that leave a workgroup zero, one or two tasks, a partial last dense tile, or exactly a tile - against the
+    per-tile kernels (the same split arithmetic in conv2-conv4, float32 conv1: within 2e-6) and the oracle."""
+    ctx = _lib.default_context()
+    m = F2CNNModel.glorot(3, rows, channels, zero_bias=False)
+    rng = np.random.default_rng(12)
+    for n in (1, 2, 63, 95, 96, 97, 193, 300, 1025):
+        x = rng.random((n, rows, channels)).astype(np.float32)
+        got = m.predict(x, ctx)
+        try:
+            ctx.set_option("cnn_ws", 0)
+            ref = m.predict(x, ctx)
+        finally:
+            ctx.set_option("cnn_ws", 1)
+        assert np.abs(got - ref).max() <= 2e-6, n
+        if n <= 97:
+            np.testing.assert_allclose(got, orc.cnn_forward(x, oracle_weights(m)), atol=2e-5)
+
+
 def test_cnn_structured_inputs():
     # a shifted impulse probes every tap / padding edge of the conv stack; zeros probe the biases
     m = F2CNNModel.glorot(11, zero_bias=False)
