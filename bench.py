@@ -115,9 +115,42 @@ def synth_corpus(seed, idx, lens, procs):
     return np.concatenate(parts)
 
 
-def host_cores(cap=16):
+def cgroup_cpu_quota():
+    """CPUs the container's cgroup lets this process use at once (cpu.max / cfs quota), or None if unlimited / unknown"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else max(1, quota // period)
+    except (OSError, ValueError):
+        return None
+
+
+def host_cores():
+    """Worker processes of the CPU baselines: every core this process may run on (its affinity mask - after the rank pinned
+    itself to its GPU's NUMA node - capped by the cgroup's CPU quota); $F2CNN_BENCH_CORES overrides. (Rounds 1-4 capped
+    this at 16; BASELINE.md section 3 plans P = os.cpu_count().)"""
+    if os.environ.get("F2CNN_BENCH_CORES"):
+        return max(1, int(os.environ["F2CNN_BENCH_CORES"]))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return max(1, min(cores, cap))   # 16 = the one-GPU box's CPU share
+    quota = cgroup_cpu_quota()
+    return max(1, min(cores, quota) if quota else cores)
+
+
+def host_core_facts(used):
+    """What the host offers beside what a baseline used, so that a reader can rescale: `cores` in a cpu_baseline is `used`."""
+    return {"cores_used": used, "cores_in_affinity_mask": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cores_of_the_host": os.cpu_count(), "cgroup_cpu_quota": cgroup_cpu_quota()}
+
+
+def all_cores_estimate(gpu_value, cpu):
+    """GPU / CPU ratio if the baseline had used every core of the host instead of `cores` (linear scaling assumed)"""
+    total = os.cpu_count() or cpu["cores"]
+    return round(gpu_value / (cpu["value"] * total / cpu["cores"]), 1)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -141,12 +174,14 @@ def cpu_baseline(seed, n, C, lpf, mode, sample):
     """Filterbank (+ envelope) of `sample` utterances of the workload, one utterance per pool task, compute only."""
     import multiprocessing as mp
     cores = host_cores()
+    sample = max(sample, 2 * cores)       # two utterances per worker at least: the pool's tail does not dominate
     with mp.get_context("spawn").Pool(cores) as pool:
         pool.map(_cpu_one, [(seed, i, 256, 8, lpf, mode) for i in range(cores)])  # start + import the workers
         t0 = time.perf_counter()
         per = pool.map(_cpu_one, [(seed, i, n, C, lpf, mode) for i in range(sample)], chunksize=1)
         wall = time.perf_counter() - t0
     return {"value": round(sample * n / FS / wall, 3), "unit": "audio-seconds/s", "cores": cores, "kind": "port",
+            "host": host_core_facts(cores),
             "sample": f"{sample} of the same synthetic utterances ({n} samples, {C} channels), oracle/f2cnn_oracle.py "
                       f"{'erb_filterbank' if mode == 'filterbank' else 'filter_and_envelope'} in a {cores}-process pool, "
                       f"compute only; {sum(per):.1f} s of CPU work in {wall:.1f} s wall",
@@ -196,6 +231,7 @@ def cpu_baseline_cnn(seed, n, windows_per_task=256):
     win = float(np.mean([p[1] + p[2] for p in per])) / windows_per_task       # s per window on one core
     per_utt_core_s = dsp + win * nb
     return {"value": round(cores * (n / FS) / per_utt_core_s, 4), "unit": "audio-seconds/s", "cores": cores, "kind": "port",
+            "host": host_core_facts(cores),
             "sample": f"{cores} pool tasks x {windows_per_task} every-sample windows of utterance 0 (filterbank + envelope "
                       f"{dsp:.2f} s, gather + normalise + oracle cnn_forward {win * 1e3:.2f} ms per window on one core, one "
                       f"BLAS thread per process), scaled to {nb} windows per utterance and {cores} cores; {wall:.1f} s wall",
@@ -522,7 +558,41 @@ def block_cfg4(ctx, coefs, precision, B, N, steps, warmup, ranks, with_cpu):
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline_cnn(SEEDS["cfg4"], N)
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        out["gpu_over_cpu_all_cores_est"] = all_cores_estimate(out["value"], out["cpu_baseline"])
     return out, prof, elapsed, flop
+
+
+def block_sustained(ctx, coefs, C, N, rank, seconds=6.0):
+    """The cfg3 step repeated for `seconds` of wall time without a pause: the rate the chip holds once clocks and
+    temperature have settled (the K timed steps of the headline are 0.1 s of GPU time), and a stretch of GPU work long
+    enough for an external utilisation sampler to see."""
+    from f2cnn_amd import _lib
+    B = 1000
+    waves = synth_batch(SEEDS["cfg3"], rank * B, B, N).reshape(-1)
+    job = DspJob(ctx, coefs, C, waves, np.full(B, N, np.int64), B, "both", 50, _lib.FFT_F32)
+    del waves
+    for _ in range(3):
+        job.step()
+    ctx.synchronize()
+    steps, t0 = 0, time.perf_counter()
+    first = last = None
+    while True:
+        t1 = time.perf_counter()
+        for _ in range(50):
+            job.step()
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        steps += 50
+        last = (t2 - t1) / 50
+        first = first if first is not None else last
+        if t2 - t0 >= seconds:
+            break
+    elapsed = time.perf_counter() - t0
+    job.free()
+    return {"workload": f"cfg3 (1000 x {N / FS:g} s, {C} channels, LPF 50) repeated for {seconds:g} s of wall time, a device sync "
+                        "every 50 steps", "value": round(B * N / FS * steps / elapsed, 1), "unit": "audio-seconds/s", "steps": steps,
+            "seconds": round(elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "ms_per_step_first_50": round(first * 1e3, 4), "ms_per_step_last_50": round(last * 1e3, 4)}
 
 
 def block_cfg1(ctx, ranks, steps=200, warmup=20):
@@ -568,7 +638,24 @@ def _e2e_cpu_one(args):
     return time.perf_counter() - t
 
 
-def block_end_to_end(n_files, cpu_files, with_cpu):
+def pcie_link(local=0):
+    """Nominal one-direction bandwidth of the PCIe link of HIP device `local`, from sysfs (no GPU call):
+    {"gpu", "speed", "width", "GBps"} or None. GT/s x lanes / 8, less the 128b/130b line code (gen 3 and later)."""
+    from f2cnn_amd.runtime import gpu_numa_nodes
+    gpus = gpu_numa_nodes()
+    if not (0 <= local < len(gpus)):
+        return None
+    bdf = gpus[local][0]
+    try:
+        speed = open(f"/sys/bus/pci/devices/{bdf}/current_link_speed").read().strip()
+        width = int(open(f"/sys/bus/pci/devices/{bdf}/current_link_width").read().strip())
+        gts = float(speed.split()[0])
+    except (OSError, ValueError, IndexError):
+        return None
+    return {"gpu": bdf, "speed": speed, "width": width, "GBps": round(gts * width / 8 * (128 / 130 if gts >= 8 else 0.8), 1)}
+
+
+def block_end_to_end(n_files, cpu_files, with_cpu, local=0):
     """File level, host I/O and PCIe included: n_files x 1 s SPHERE files on tmpfs through the CLI drivers
     (`prepare filter` + `prepare envelope`, and the one-pass `prepare features`), and the oracle + numpy.save
     equivalent on the host cores beside it. Never the bench `value`."""
@@ -603,6 +690,15 @@ def block_end_to_end(n_files, cpu_files, with_cpu):
                "two_commands_audio_s_per_s": round(n_files / (t1 + t2), 1),
                "prepare_features_s": round(t3, 3), "one_pass_audio_s_per_s": round(n_files / t3, 1),
                "npy_bytes_per_pass": n_files * 2 * 128 * FS * 8}
+        # this block's roofline is the PCIe link: every .npy byte crosses it once (device -> host), the waves the other way
+        out["npy_GBps"] = round(out["npy_bytes_per_pass"] / t3 / 1e9, 1)
+        out["npy_GBps_two_commands"] = round((out["npy_bytes_per_pass"] + n_files * 128 * FS * 8) / (t1 + t2) / 1e9, 1)
+        link = pcie_link(local)
+        out["pcie_link"] = link
+        if link:
+            out["npy_frac_of_pcie"] = round(out["npy_GBps"] / link["GBps"], 3)
+            out["note"] = ("bound by the PCIe link and numpy.save, not by the kernels: npy_GBps = .GFB.npy + .ENV1.npy bytes of one "
+                           "`prepare features` pass / its wall time; two commands also read the .GFB.npy files back")
         if with_cpu:
             cores = host_cores()
             cpu_files = min(cpu_files, n_files)
@@ -615,7 +711,9 @@ def block_end_to_end(n_files, cpu_files, with_cpu):
                                    "kind": "port", "sample": f"{cpu_files} of the same files: read, oracle filterbank, "
                                    f"numpy.save GFB, numpy.load, oracle envelope (LPF 50), numpy.save ENV1, one file per "
                                    f"task in a {cores}-process pool; {wall:.1f} s wall"}
+            out["cpu_baseline"]["host"] = host_core_facts(cores)
             out["two_commands_over_cpu"] = round(out["two_commands_audio_s_per_s"] / out["cpu_baseline"]["value"], 1)
+            out["two_commands_over_cpu_all_cores_est"] = all_cores_estimate(out["two_commands_audio_s_per_s"], out["cpu_baseline"])
         return out
     finally:
         os.chdir(cwd)
@@ -710,6 +808,7 @@ def main():
                    "kernels": blk["kernels_ms_per_step"], "cpu_baseline": blk.get("cpu_baseline")}
             if out["cpu_baseline"]:
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+                out["gpu_over_cpu_all_cores_est"] = all_cores_estimate(out["value"], out["cpu_baseline"])
     else:
         if args.steps == 20 and args.warmup == 3 and workload == "cfg5r":
             args.steps, args.warmup = 3, 1
@@ -727,6 +826,7 @@ def main():
                 n_cpu = N if workload != "cfg5r" else 40000
                 out["cpu_baseline"] = cpu_baseline(seed, n_cpu, C, run["lpf"], run["mode"], args.cpu_sample)
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+                out["gpu_over_cpu_all_cores_est"] = all_cores_estimate(out["value"], out["cpu_baseline"])
 
     # side blocks: the other configurations in the same line (default runs only)
     blocks = {}
@@ -736,6 +836,7 @@ def main():
                     "steps": r["steps"], "ms_per_step": r["ms_per_step"], "scaling": r["scaling"],
                     "step_frac_of_hbm_peak": r["roofline"]["step"]["frac"], "kernels": r["kernels"]}
         if world == 1:
+            blocks["cfg3_sustained"] = block_sustained(ctx, coefs, C, N, rank)
             blocks["cfg3_fft_f64"] = brief(dsp_run(ctx, ranks, coefs, C, N, "cfg3", "f64", 5, 1, args.batch, args.corpus))
             blocks["cfg5"] = brief(dsp_run(ctx, ranks, coefs, C, N, "cfg5", "f32", 2, 1, None, args.corpus))
         r = dsp_run(ctx, ranks, coefs, C, N, "cfg5r", "f32", 2, 1, None, args.corpus)
@@ -756,7 +857,7 @@ def main():
         if world == 1:
             ctx.synchronize()
             try:
-                blocks["end_to_end"] = block_end_to_end(args.e2e_files, 128, with_cpu)
+                blocks["end_to_end"] = block_end_to_end(args.e2e_files, 128, with_cpu, local)
             except Exception as exc:       # a full tmpfs must not lose the kernel numbers
                 blocks["end_to_end"] = {"error": repr(exc)}
         if rank == 0 and out is not None:
@@ -772,6 +873,8 @@ def main():
                 out["value_ragged"] = blocks["cfg5_ragged"]["value"]
             if "cfg1" in blocks:
                 out["cfg1_latency_us"] = blocks["cfg1"]["latency_us"]
+            if "cfg3_sustained" in blocks:
+                out["value_sustained"] = blocks["cfg3_sustained"]["value"]
             if "cfg4" in blocks and "cnn" in blocks["cfg4"]:
                 out["cnn_issued_frac_of_bf16_peak"] = blocks["cfg4"]["cnn"].get("frac")
                 out["cnn_algorithmic_frac_of_bf16_peak"] = blocks["cfg4"]["cnn"].get("algorithmic_frac_of_bf16_peak")

@@ -34,6 +34,7 @@ SIGNATURES = {
     "f2_last_error": (C.c_char_p, [_vp]),
     "f2_ctx_set_option": (_i, [_vp, C.c_char_p, _d]),
     "f2_ctx_get_option": (_i, [_vp, C.c_char_p, _P(_d)]),
+    "f2_spectral_guard_read": (_i, [_vp, _vp, _i64, _P(_i64)]),
     "f2_dev_malloc": (_i, [_vp, C.c_size_t, _P(_vp)]),
     "f2_dev_free": (_i, [_vp, _vp]),
     "f2_dev_memset": (_i, [_vp, _vp, _i, C.c_size_t]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     "f2_gather_windows": (_i, [_vp, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _vp, _i]),
     "f2_cnn_create": (_i, [_vp, _P(_vp), _i, _i, _P(_vp)]),
     "f2_cnn_destroy": (_i, [_vp, _vp]),
+    "f2_cnn_get_info": (_i, [_vp, _vp, C.c_char_p, _P(_d)]),
     "f2_cnn_forward": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i]),
     "f2_eval_utterance": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _i, _i, _d, _i, _i, _i, _vp, _vp, _vp, _P(_i64), _i]),
     "f2_eval_batch": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _d, _i, _i, _i, _vp, _vp, _i]),
@@ -183,6 +185,16 @@ class Context:
         self.check(self.lib.f2_ctx_get_option(self.handle, key.encode(), C.byref(v)))
         return v.value
 
+    def spectral_guard_values(self):
+        """(rows, 4) float32 {row max, padding residual, low-passed row max, flagged} of the last fused call made with option
+        spectral_guard_dump = 1, rows in (utterance, channel) batch order; NaN rows were not served by the spectral kernel."""
+        avail = _i64()
+        self.check(self.lib.f2_spectral_guard_read(self.handle, None, 0, C.byref(avail)))
+        out = np.empty((avail.value, 4), np.float32)
+        if avail.value:
+            self.check(self.lib.f2_spectral_guard_read(self.handle, out.ctypes.data, avail.value, None))
+        return out
+
     def options(self, **kv):
         """Context manager: set the given options, restore the previous values on exit."""
         ctx = self
@@ -292,6 +304,12 @@ class Context:
         h = _vp()
         self.check(self.lib.f2_cnn_create(self.handle, ptrs, int(rows), int(channels), C.byref(h)))
         return h
+
+    def cnn_info(self, handle, key):
+        """f2_cnn_get_info: 'ws_ok', 'ws_dense_ok', 'ws_check_diff', 'ws_dense_check_diff', 'flat'"""
+        v = _d()
+        self.check(self.lib.f2_cnn_get_info(self.handle, handle, key.encode(), C.byref(v)))
+        return v.value
 
     def cnn_destroy(self, handle):
         self.check(self.lib.f2_cnn_destroy(self.handle, handle))

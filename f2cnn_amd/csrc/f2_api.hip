@@ -35,15 +35,45 @@ int f2_reserve(f2_ctx* ctx, f2_scratch& s, size_t bytes) {
 int f2_upload_async(f2_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
     if (bytes == 0) return F2_OK;
     constexpr size_t RING = size_t(8) << 20, ALIGN = 256;
-    // finished one-off buffers of earlier large uploads
-    for (size_t i = 0; i < ctx->up_big.size();) {
-        if (hipEventQuery(ctx->up_big[i].second) == hipSuccess) {
-            (void)hipHostFree(ctx->up_big[i].first);
-            ctx->prof_pool.push_back(ctx->up_big[i].second);
-            ctx->up_big.erase(ctx->up_big.begin() + (long)i);
-        } else {
-            ++i;
+    if (bytes > RING / 4) {
+        // Large uploads (the `centers` array of f2_gather_windows, twiddle tables) go through a few grow-only page-locked
+        // side buffers that are reused once the copy that read them has finished: a hipHostMalloc / hipHostFree pair per
+        // call is slow and can serialise with the device (round-4 advisor finding).
+        f2_ctx::up_side* pick = nullptr;   // the smallest idle buffer that is large enough, else the smallest idle one (to be grown)
+        for (f2_ctx::up_side& b : ctx->up_big) {
+            if (b.busy && hipEventQuery(b.done) == hipSuccess) b.busy = false;
+            if (b.busy) continue;
+            const bool fits = b.cap >= bytes, cur_fits = pick && pick->cap >= bytes;
+            if (!pick || (fits && !cur_fits) || (fits == cur_fits && b.cap < pick->cap)) pick = &b;
         }
+        if (!pick && ctx->up_big.size() >= 4) {   // all busy: wait for the oldest rather than pinning ever more memory
+            pick = &ctx->up_big.front();
+            F2_HIP(ctx, hipEventSynchronize(pick->done));
+            pick->busy = false;
+        }
+        if (!pick) {
+            hipEvent_t ev;
+            F2_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->up_big.push_back({nullptr, 0, ev, false});
+            pick = &ctx->up_big.back();
+        }
+        if (pick->cap < bytes) {
+            if (pick->ptr) (void)hipHostFree(pick->ptr);
+            pick->ptr = nullptr;
+            pick->cap = 0;
+            const size_t want = std::max(bytes + bytes / 4, size_t(4) << 20);
+            hipError_t e = hipHostMalloc(&pick->ptr, want, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                pick->ptr = nullptr;
+                return f2_fail(ctx, F2_ERR_NOMEM, "hipHostMalloc(%zu) -> %s", want, hipGetErrorString(e));
+            }
+            pick->cap = want;
+        }
+        memcpy(pick->ptr, src, bytes);
+        F2_HIP(ctx, hipMemcpyAsync(d_dst, pick->ptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+        pick->busy = true;     // (set before the record: if that fails the buffer is waited for by event query -> stays busy
+        F2_HIP(ctx, hipEventRecord(pick->done, ctx->stream));   //  until the slow path above synchronises on it)
+        return F2_OK;
     }
     hipEvent_t ev;
     if (!ctx->prof_pool.empty()) {
@@ -52,16 +82,15 @@ int f2_upload_async(f2_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
     } else {
         F2_HIP(ctx, hipEventCreate(&ev));
     }
-    if (bytes > RING / 4) {
-        void* h = nullptr;
-        hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocDefault);
-        if (e != hipSuccess) return f2_fail(ctx, F2_ERR_NOMEM, "hipHostMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
-        memcpy(h, src, bytes);
-        F2_HIP(ctx, hipMemcpyAsync(d_dst, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-        F2_HIP(ctx, hipEventRecord(ev, ctx->stream));
-        ctx->up_big.push_back({h, ev});
-        return F2_OK;
-    }
+    // (from here on an early return hands `ev` back to the pool)
+    struct ev_guard {
+        f2_ctx* c;
+        hipEvent_t e;
+        bool armed;
+        ~ev_guard() {
+            if (armed) c->prof_pool.push_back(e);
+        }
+    } guard{ctx, ev, true};
     if (!ctx->up_ring) {
         F2_HIP(ctx, hipHostMalloc((void**)&ctx->up_ring, RING, hipHostMallocDefault));
         ctx->up_cap = RING;
@@ -84,6 +113,7 @@ int f2_upload_async(f2_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
     memcpy(ctx->up_ring + begin, src, bytes);
     F2_HIP(ctx, hipMemcpyAsync(d_dst, ctx->up_ring + begin, bytes, hipMemcpyHostToDevice, ctx->stream));
     F2_HIP(ctx, hipEventRecord(ev, ctx->stream));
+    guard.armed = false;
     ctx->up_inflight.push_back({begin, begin + need, ev});
     ctx->up_head = begin + need;
     return F2_OK;
@@ -124,7 +154,7 @@ int f2_prof_end(f2_ctx* ctx, int kernel_id) {
 
 extern "C" {
 
-int f2_version(void) { return 104; }   // 101: f2_eval_batch; 102: f2_host_alloc, F2_MEM_HOST_ASYNC; 103: f2_ctx_set_option; 104: f2_event_query
+int f2_version(void) { return 105; }   // 101: f2_eval_batch; 102: f2_host_alloc, F2_MEM_HOST_ASYNC; 103: f2_ctx_set_option; 104: f2_event_query; 105: f2_spectral_guard_read
 
 int f2_device_count(int* count) {
     if (!count) return f2_fail(nullptr, F2_ERR_INVALID, "count is NULL");
@@ -224,8 +254,8 @@ int f2_ctx_destroy(f2_ctx* ctx) {
             if (sc.ptr) (void)hipFree(sc.ptr);
     for (auto& sp : ctx->up_inflight) (void)hipEventDestroy(sp.done);
     for (auto& b : ctx->up_big) {
-        (void)hipHostFree(b.first);
-        (void)hipEventDestroy(b.second);
+        if (b.ptr) (void)hipHostFree(b.ptr);
+        (void)hipEventDestroy(b.done);
     }
     if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
@@ -269,6 +299,8 @@ const opt_entry kOptions[] = {
     {"spectral", &f2_ctx::opt_spectral, nullptr, 0, 1},
     {"spectral_tol", nullptr, &f2_ctx::opt_spectral_tol, 0, 1},
     {"spectral_min_rows", &f2_ctx::opt_spectral_min_rows, nullptr, 0, 1 << 30},
+    {"spectral_min_pad", &f2_ctx::opt_spectral_min_pad, nullptr, -1, 1 << 16},
+    {"spectral_guard_dump", &f2_ctx::opt_spectral_guard_dump, nullptr, 0, 1},
     {"k1_split", &f2_ctx::opt_k1_split, nullptr, -1, 64},
     {"k1_queue", &f2_ctx::opt_k1_queue, nullptr, -1, 1},
     {"k1_qwaves", &f2_ctx::opt_k1_qwaves, nullptr, 0, 1 << 20},
@@ -338,6 +370,18 @@ int f2_ctx_get_option(f2_ctx* ctx, const char* key, double* value) {
     const opt_entry* e = find_option(key);
     F2_CHECK(ctx, e && value, F2_ERR_INVALID, "unknown option '%s'", key ? key : "(null)");
     *value = e->ifield ? (double)(ctx->*(e->ifield)) : (double)(ctx->*(e->ffield));
+    return F2_OK;
+}
+
+int f2_spectral_guard_read(f2_ctx* ctx, float* out, int64_t rows, int64_t* rows_available) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, rows >= 0 && (out || rows == 0), F2_ERR_INVALID, "bad output buffer");
+    if (rows_available) *rows_available = (int64_t)ctx->spec_gdump_rows;
+    const size_t take = std::min((size_t)rows, ctx->spec_gdump_rows);
+    if (take == 0) return F2_OK;
+    F2_HIP(ctx, hipSetDevice(ctx->device));
+    F2_HIP(ctx, hipMemcpyAsync(out, ctx->spec_gdump.ptr, sizeof(float) * 4 * take, hipMemcpyDeviceToHost, ctx->stream));
+    F2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return F2_OK;
 }
 
@@ -667,14 +711,14 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
     const int* d_uflag = nullptr;
     ctx->spec_last_B = 0;
     if (ctx->opt_spectral && fft_precision == F2_FFT_F32 && !d_gfb && ctx->spec_coefs_ok < 0)
-        ctx->spec_coefs_ok = f2_spectral_supports_coefs(ctx->coefs_host, C, nullptr) ? 1 : 0;   // (once per table: ~50 us of logarithms)
+        ctx->spec_coefs_ok = f2_spectral_supports_coefs(ctx->coefs_host, C, nullptr, &ctx->spec_min_pad) ? 1 : 0;   // (once per table: ~50 us of logarithms)
     if (ctx->opt_spectral && fft_precision == F2_FFT_F32 && !d_gfb && ctx->spec_coefs_ok == 1) {
         std::vector<int> meta((size_t)B, 1);
         std::vector<int> lists[F2_SPECTRAL_MAX_LOG2H + 1];
         int nspec = 0;
         for (int b = 0; b < B; ++b) {
             const int64_t n = offsets[b + 1] - offsets[b];
-            if (!f2_spectral_supports_len(n)) continue;
+            if (!f2_spectral_supports_len(n, ctx->opt_spectral_min_pad >= 0 ? ctx->opt_spectral_min_pad : ctx->spec_min_pad)) continue;
             lists[f2_log2_ceil(n) - 1].push_back(b);
             meta[(size_t)b] = 0;
             ++nspec;
@@ -697,6 +741,13 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
             }
             int* uflag = (int*)ctx->spec_uflag.ptr;
             F2_HIP(ctx, hipMemcpyAsync(uflag, ctx->spec_meta.ptr, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, ctx->stream));
+            ctx->spec_gdump_rows = 0;
+            if (ctx->opt_spectral_guard_dump) {   // diagnostic: rows the spectral kernel does not serve read back as -1
+                const size_t gbytes = sizeof(float) * 4 * (size_t)B * (size_t)C;
+                F2_TRY(f2_reserve(ctx, ctx->spec_gdump, gbytes));
+                F2_HIP(ctx, hipMemsetAsync(ctx->spec_gdump.ptr, 0xff, gbytes, ctx->stream));
+                ctx->spec_gdump_rows = (size_t)B * (size_t)C;
+            }
             for (int l = F2_SPECTRAL_MIN_LOG2H; l <= F2_SPECTRAL_MAX_LOG2H; ++l)
                 F2_TRY(f2_launch_spectral(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, (const double*)ctx->coefs.ptr,
                                           C, (const int*)ctx->spec_meta.ptr + pos[l], (int)lists[l].size(), l, lpf, cutoff_hz,

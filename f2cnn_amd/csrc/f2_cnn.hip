@@ -1069,7 +1069,7 @@ int f2_launch_cnn_convs(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_
     float* a2 = d_ws;
     float* a3 = a2 + (size_t)n * d.Hp1 * d.Wp1 * C2;
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
-    const bool ws = ctx->opt_cnn_bf16x3 && ctx->opt_cnn_ws && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels);
+    const bool ws = ctx->opt_cnn_bf16x3 && ctx->opt_cnn_ws && cnn->ws_ok && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels);
     if (ws) {
         // weight-stationary persistent kernels (f2_cnn_ws.hip): conv1 on the matrix cores, one barrier per tile
         F2_TRY(f2_launch_cnn_ws(ctx, cnn, d_x, n, a2, a4));
@@ -1129,8 +1129,8 @@ int f2_launch_cnn_dense(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t
     if (n <= 0) return F2_OK;
     const Dims d = make_dims(cnn->rows, cnn->channels);
     F2_TRY(f2_prof_begin(ctx, F2_K_CNN));
-    const bool ws = ctx->opt_cnn_bf16x3 && ctx->opt_cnn_ws && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels);
-    if (ws && ctx->opt_cnn_ws_dense && d.flat % 64 == 0 && d.flat >= 128 && n * (int64_t)d.flat * 4 < (int64_t(1) << 32)) {
+    const bool ws = ctx->opt_cnn_bf16x3 && ctx->opt_cnn_ws && cnn->ws_ok && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels);
+    if (ws && ctx->opt_cnn_ws_dense && cnn->ws_dense_ok && d.flat % 64 == 0 && d.flat >= 128 && n * (int64_t)d.flat * 4 < (int64_t(1) << 32)) {
         F2_TRY(f2_launch_dense1_ws(ctx, cnn, a4, n, d.flat, a5));
     } else {
         const dim3 grid((unsigned)((n + 32 * D1_MT - 1) / (32 * D1_MT)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
@@ -1150,6 +1150,80 @@ int f2_launch_cnn_dense(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t
                        cnn->t(11), d_scores, d_labels, n);
     F2_HIP(ctx, hipGetLastError());
     F2_TRY(f2_prof_end(ctx, F2_K_CNN));
+    return F2_OK;
+}
+
+// The weight-stationary kernels (f2_cnn_ws.hip) issue their global loads through inline asm and wait for them with hand-
+// counted s_waitcnt; the compiler believes a loaded register valid at once, so a copy or spill it placed between load and
+// wait would read stale data without any diagnostic - their correctness depends on the register allocation of the hipcc
+// that built this library (round-4 advisor finding). So every network is run once, on a fixed batch, through those kernels
+// and through the per-tile split-bf16 kernels (compiler-scheduled waits); a kernel that disagrees beyond the rounding level
+// of the two summation orders is switched off for this network, loudly.
+static int cnn_ws_selfcheck(f2_ctx* ctx, f2_cnn* cnn) {
+    if (!cnn->blob16 || !f2_cnn_ws_supported(cnn->rows, cnn->channels)) return F2_OK;
+    constexpr int NCHK = 200;    // two 96-window dense tiles + a partial one
+    constexpr float TOL = 5e-6f;  // softmax scores; the two paths agree to ~1e-6 (tests/test_gpu_windows_cnn.py)
+    const size_t per = (size_t)cnn->rows * cnn->channels;
+    std::vector<float> x(per * NCHK);
+    uint32_t lcg = 12345u;
+    for (float& v : x) {
+        lcg = lcg * 1664525u + 1013904223u;
+        v = (float)(lcg >> 8) * (1.0f / 16777216.0f);
+    }
+    float *d_x = nullptr, *d_ws = nullptr, *d_sc = nullptr;
+    const size_t wsf = f2_cnn_workspace_floats(cnn) * NCHK;
+    auto cleanup = [&]() {
+        if (d_x) (void)hipFree(d_x);
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_sc) (void)hipFree(d_sc);
+    };
+    if (hipMalloc((void**)&d_x, x.size() * 4) != hipSuccess || hipMalloc((void**)&d_ws, wsf * 4) != hipSuccess ||
+        hipMalloc((void**)&d_sc, 3 * 2 * NCHK * 4) != hipSuccess) {
+        cleanup();
+        return f2_fail(ctx, F2_ERR_NOMEM, "self-check buffers of the CNN kernels");
+    }
+    const int o_b = ctx->opt_cnn_bf16x3, o_w = ctx->opt_cnn_ws, o_d = ctx->opt_cnn_ws_dense;
+    const bool prof = ctx->prof_on;
+    ctx->prof_on = false;
+    int rc = F2_OK;
+    hipError_t e = hipMemcpyAsync(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    const int cfgs[3][2] = {{0, 0}, {1, 0}, {1, 1}};   // per-tile kernels; ws convolutions; ws convolutions + ws dense1
+    for (int k = 0; k < 3 && e == hipSuccess && rc == F2_OK; ++k) {
+        ctx->opt_cnn_bf16x3 = 1;
+        ctx->opt_cnn_ws = cfgs[k][0];
+        ctx->opt_cnn_ws_dense = cfgs[k][1];
+        rc = f2_launch_cnn(ctx, cnn, d_x, NCHK, d_ws, d_sc + (size_t)k * 2 * NCHK, nullptr);
+    }
+    ctx->opt_cnn_bf16x3 = o_b;
+    ctx->opt_cnn_ws = o_w;
+    ctx->opt_cnn_ws_dense = o_d;
+    ctx->prof_on = prof;
+    std::vector<float> sc(3 * 2 * NCHK);
+    if (e == hipSuccess && rc == F2_OK) e = hipMemcpyAsync(sc.data(), d_sc, sc.size() * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == F2_OK) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (rc != F2_OK) return rc;
+    if (e != hipSuccess) return f2_fail(ctx, F2_ERR_HIP, "self-check of the CNN kernels -> %s", hipGetErrorString(e));
+    auto maxdiff = [&](int a, int b) {
+        float m = 0.f;
+        for (int i = 0; i < 2 * NCHK; ++i) {
+            const float dv = fabsf(sc[(size_t)a * 2 * NCHK + i] - sc[(size_t)b * 2 * NCHK + i]);
+            m = dv == dv ? fmaxf(m, dv) : INFINITY;   // NaN counts as a mismatch
+        }
+        return m;
+    };
+    cnn->ws_check_diff = maxdiff(1, 0);
+    cnn->ws_dense_check_diff = maxdiff(2, 1);
+    if (!(cnn->ws_check_diff <= TOL)) {
+        cnn->ws_ok = cnn->ws_dense_ok = false;
+        fprintf(stderr, "[libf2cnn_hip] weight-stationary CNN kernels disagree with the per-tile kernels by %.3g on the "
+                        "self-check batch (built by another hipcc than they were validated with?): not used for this network\n",
+                (double)cnn->ws_check_diff);
+    } else if (!(cnn->ws_dense_check_diff <= TOL)) {
+        cnn->ws_dense_ok = false;
+        fprintf(stderr, "[libf2cnn_hip] weight-stationary dense1 kernel disagrees with the per-tile kernel by %.3g on the "
+                        "self-check batch: not used for this network\n", (double)cnn->ws_dense_check_diff);
+    }
     return F2_OK;
 }
 
@@ -1279,7 +1353,26 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
         delete cnn;
         return f2_fail(ctx, F2_ERR_HIP, "uploading CNN weights -> %s", hipGetErrorString(e));
     }
+    const int rc = cnn_ws_selfcheck(ctx, cnn);
+    if (rc != F2_OK) {
+        (void)hipFree(cnn->blob);
+        (void)hipFree(cnn->blob16);
+        delete cnn;
+        return rc;
+    }
     *out = cnn;
+    return F2_OK;
+}
+
+int f2_cnn_get_info(f2_ctx* ctx, const f2_cnn* cnn, const char* key, double* value) {
+    F2_CHECK(nullptr, ctx, F2_ERR_INVALID, "ctx is NULL");
+    F2_CHECK(ctx, cnn && key && value, F2_ERR_INVALID, "null argument");
+    if (strcmp(key, "ws_ok") == 0) *value = cnn->ws_ok && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels) ? 1.0 : 0.0;
+    else if (strcmp(key, "ws_dense_ok") == 0) *value = cnn->ws_dense_ok && cnn->ws_ok && cnn->blob16 && f2_cnn_ws_supported(cnn->rows, cnn->channels) ? 1.0 : 0.0;
+    else if (strcmp(key, "ws_check_diff") == 0) *value = (double)cnn->ws_check_diff;
+    else if (strcmp(key, "ws_dense_check_diff") == 0) *value = (double)cnn->ws_dense_check_diff;
+    else if (strcmp(key, "flat") == 0) *value = (double)cnn->flat;
+    else return f2_fail(ctx, F2_ERR_INVALID, "unknown key '%s'", key);
     return F2_OK;
 }
 

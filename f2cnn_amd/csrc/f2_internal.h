@@ -72,8 +72,11 @@ struct f2_ctx {
     f2_scratch spec_x, spec_rho;          // utterance spectra, per-row digits of the launch in flight
     f2_scratch spec_xpart;                // float64 partial spectra of decimated (long) utterances
     f2_scratch spec_meta, spec_uflag;     // [initial flags (B) | utterance lists]; the flags the kernels update
+    f2_scratch spec_gdump;                // [B][C][4] floats, option "spectral_guard_dump"
+    size_t spec_gdump_rows = 0;           // B x C of the call that filled it
     std::vector<int> spec_meta_host;      // what spec_meta currently holds
     int spec_coefs_ok = -1;               // coefs_host eligible for the spectral kernel: -1 not decided, 0, 1
+    int spec_min_pad = 64;                // ... and the padding samples its accuracy guard needs (ringing peak of the slowest channel)
     size_t spec_last_B = 0;               // batch size of the last fused call that used the spectral kernel (0: none)
     f2_scratch tw_sp[2][16];              // its twiddle tables, [precision][log2 H]
     f2_scratch spec_lptab;                // low-pass powers per thread (lowpass_pairs_store_tab) ...
@@ -82,7 +85,9 @@ struct f2_ctx {
     // options (f2_ctx_set_option); -1 = decide from the batch
     int opt_spectral = 1;                 // route eligible utterances of the fused call through the spectral kernel
     int opt_spectral_min_rows = 4096;     // ... when the call has at least this many eligible rows (utterances x channels)
-    float opt_spectral_tol = 4e-6f;       // accuracy guard: padding residual / row maximum that flags an utterance
+    float opt_spectral_tol = 4e-6f;       // accuracy guard: padding residual / maximum of the delivered row that flags an utterance
+    int opt_spectral_min_pad = -1;        // padding samples a row needs for that route: -1 = from the coefficient table, else >= 64
+    int opt_spectral_guard_dump = 0;      // diagnostic: keep the guard's per-row values of the last fused call (f2_spectral_guard_read)
     int opt_k1_split = -1;                // segments of the time-split filterbank (0 = never, >= 2 = force)
     int opt_k1_queue = -1;                // unit queue of the filterbank for ragged batches (0 / 1)
     int opt_k1_qwaves = 0;                // waves of the queue launch (0 = from the batch)
@@ -101,7 +106,13 @@ struct f2_ctx {
         hipEvent_t done;
     };
     std::vector<up_span> up_inflight;                  // oldest first
-    std::vector<std::pair<void*, hipEvent_t>> up_big;   // one-off page-locked buffers of large uploads, freed once copied
+    struct up_side {
+        void* ptr;
+        size_t cap;
+        hipEvent_t done;   // recorded behind the last copy that read from the buffer
+        bool busy;         // `done` not yet seen reached
+    };
+    std::vector<up_side> up_big;   // grow-only page-locked side buffers of uploads too large for the ring, reused once copied
     f2_scratch flags;      // small device words (error flags)
     int* host_flags = nullptr;  // pinned mirror
 };
@@ -115,6 +126,11 @@ struct f2_cnn {
     uint16_t* blob16 = nullptr;  // conv2 .. conv4 and dense1 kernels split into two bf16 pieces (f2_cnn.hip, k_*_bf16x3)
     size_t off16[4] = {0};       // element offsets of the four layers in `blob16`
     const void* zeros = nullptr; // 256 zero bytes behind them (source of the padding pixels of f2_cnn_ws.hip's LDS-DMA loads)
+    // f2_cnn_create's self-check of the weight-stationary kernels (hand-placed s_waitcnt around inline-asm loads: correct only
+    // while the register allocator of the hipcc that built the library leaves those registers alone) against the per-tile
+    // split-bf16 kernels on a fixed batch; a kernel that disagrees is not used with this network
+    bool ws_ok = true, ws_dense_ok = true;
+    float ws_check_diff = -1.f, ws_dense_check_diff = -1.f;   // max |score difference| measured (-1: not applicable)
 };
 
 // activation workspace (floats) the CNN needs per window
@@ -219,8 +235,8 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
                        const f2_handoff* handoff = nullptr, const int* d_uflag = nullptr);
 // Spectral filterbank + envelope (f2_spectral.hip): which utterances / coefficient tables it serves, and the launch for
 // the utterances d_ulist[0..nutt) (all of length class log2h). Rows that fail its accuracy guard set d_uflag[b].
-bool f2_spectral_supports_len(int64_t n);
-bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::vector<int>* Lgroup);
+bool f2_spectral_supports_len(int64_t n, int min_pad);
+bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::vector<int>* Lgroup, int* min_pad);
 int f2_launch_spectral(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets, const double* d_coefs,
                        int C, const int* d_ulist, int nutt, int log2h, int lpf, double cutoff_hz, double* d_env, int* d_uflag);
 // d_centers == NULL: window e is centred at first_center + e

@@ -33,7 +33,8 @@
 // anyway: the real part of a over the padding region [n, M) - the zero-padded row itself, zero in exact arithmetic
 // (the imaginary part is not: a Hilbert transform is not time-limited) - measures the error directly;
 // if its maximum exceeds `tol` x the row's maximum the utterance is flagged and the caller's K1 -> K2 launches (which skip
-// unflagged utterances) recompute it. Utterances with fewer than 64 padding samples are never routed here.
+// unflagged utterances) recompute it. Utterances with fewer padding samples than the slowest channel's ringing needs to
+// reach its peak (f2_spectral_supports_len) are never routed here.
 //
 // Traffic: 8 bytes written per sample-channel (the ENV1 rows); tables (1 MB per XCD for 128 channels), utterance
 // spectra (64 KB per utterance, shared by its C rows) and 32 bytes of digits per row come from L2. Bound: f32 VALU +
@@ -152,8 +153,9 @@ constexpr size_t lowpass_tab_lds_bytes() {
 // (q^2)^((lane & 31) + 1)}. All threads call it, after a barrier that makes `smem` free.
 // CHAINED (rows longer than one sweep of the workgroup, k_spectral_envelope_long): the pairs are those of the samples from
 // `ibase` on, e_in = e[ibase - 1], *ychain = y[ibase - 1] on entry and y[ibase + 2 NT NBLK - 1] on return.
+// Returns this thread's maximum of |y| over the samples it stored (the accuracy guard's denominator when the low-pass is on).
 template <int NT, int NBLK, bool CHAINED = false>
-__device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK], const float (&ei)[NBLK], const LowpassConsts& K,
+__device__ __forceinline__ float lowpass_pairs_store_tab(const float (&er)[NBLK], const float (&ei)[NBLK], const LowpassConsts& K,
                                                         const f2_f4* __restrict__ lptab, unsigned char* smem,
                                                         double* __restrict__ y, int n, int tid, int ibase = 0, float e_in = 0.f,
                                                         double* ychain = nullptr) {
@@ -224,6 +226,7 @@ __device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK],
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t yb = CHAINED ? row_buffer_uniform(y, n) : row_buffer(y, n);
+    float ymax = 0.f;
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) {
         const float cw = cwl[jj * NW + wv];
@@ -232,8 +235,14 @@ __device__ __forceinline__ void lowpass_pairs_store_tab(const float (&er)[NBLK],
         const float sprev = lane > 0 ? up : cw;                // ... at the end of the previous pair
         const float y0 = fmaf(K.qf, fmaf(tc.y, ycar[jj], sprev), u0[jj]);
         const float y1 = fmaf(K.qf, y0, u1[jj]);
-        store_row_pair_buf(yb, n, ibase + 2 * (tid + NT * jj), (double)y0, (double)y1);
+        const int i0 = ibase + 2 * (tid + NT * jj);
+        store_row_pair_buf(yb, n, i0, (double)y0, (double)y1);
+        // (block boundaries are wave-uniform: only the block that holds sample n - 1 masks per lane)
+        const int lo = ibase + 2 * NT * jj;
+        if (lo + 2 * NT <= n) ymax = fmaxf(ymax, fmaxf(fabsf(y0), fabsf(y1)));
+        else if (lo < n) ymax = fmaxf(ymax, fmaxf(i0 < n ? fabsf(y0) : 0.f, i0 + 1 < n ? fabsf(y1) : 0.f));
     }
+    return ymax;
 }
 
 // (the read-only tables are separate __restrict__ kernel arguments: pointers inside a by-value struct carry no
@@ -248,6 +257,7 @@ struct SpecParams {
     int lpf;
     LowpassConsts lp;
     float tol;
+    float* gdump;             // diagnostic (option "spectral_guard_dump"): [B][C][4] {row max, padding residual, low-passed row max, flagged}
     unsigned long long* stamps;   // diagnostic build only
 };
 
@@ -299,6 +309,35 @@ __device__ __forceinline__ float wave_max63(float v) {
     return v;
 }
 
+// max |Re a| over this thread's samples in the padding region [n, M): v[brev(j)] = sample 2 (tid + NT j) + odd. One
+// wave-uniform branch: rows whose padding lies in the last block only (every 1 s row of a 16384-point class) look at one value.
+template <int R0, int NT>
+__device__ __forceinline__ float pad_residual(const cpx<float> (&v)[R0], int n, int tid, int odd, float gout) {
+    // sample 2 (tid + NT j) + odd >= n  <=>  j >= jmin (one register; the compiler would otherwise keep sixteen sample indices)
+    int jmin = (n - 2 * tid - odd + 2 * NT - 1) >> (__builtin_ctz(2 * NT));
+    asm volatile("" : "+v"(jmin));
+    // (rows of this length class have n > M / 2: the first half of the blocks never holds padding)
+#pragma unroll
+    for (int j = R0 / 2; j < R0; ++j) gout = fmaxf(gout, j >= jmin ? fabsf(v[brev<R0>(j)].re) : 0.f);
+    return gout;
+}
+
+// one thread per row, after the barrier behind the last atomicMax: flag the utterance if the padding-region residual exceeds
+// tol x the maximum of the row AS DELIVERED (low-passed when the low-pass is on)
+__device__ __forceinline__ void guard_decide(const SpecParams& P, const unsigned* guard, int b, int c) {
+    const float gi = __uint_as_float(guard[0]), go = __uint_as_float(guard[1]), gl = __uint_as_float(guard[2]);
+    const float den = P.lpf ? gl : gi;
+    const bool flag = go > P.tol * den;
+    if (flag) P.uflag[b] = 1;
+    if (P.gdump) {
+        float* g = P.gdump + ((size_t)b * (size_t)P.C + (size_t)c) * 4;
+        g[0] = gi;
+        g[1] = go;
+        g[2] = gl;
+        g[3] = flag ? 1.f : 0.f;
+    }
+}
+
 template <int LOG2H>
 __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float, LOG2H>())) void k_spectral_envelope(
     SpecParams P, const cpx<float>* __restrict__ Xall /* utterance spectra */, const f2_f4* __restrict__ HUall,
@@ -321,7 +360,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     constexpr int TWL = plan_tw_lds_count(LOG2H);
     __shared__ __attribute__((aligned(16))) cpx<float> twl[TWL > 0 ? TWL : 1];
-    __shared__ unsigned guard[2];   // max |a| inside [0, n) / inside [n, M), as float bits (values >= 0)
+    __shared__ unsigned guard[3];   // max |a| inside [0, n) / Re a inside [n, M) / low-passed row maximum, as float bits (>= 0)
     cpx<float>* lds = reinterpret_cast<cpx<float>*>(smem);
 
     const int tid = threadIdx.x;
@@ -358,7 +397,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
 #endif
     F2_SSTAMP(0);
     for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2H, 1) + i];
-    if (tid < 2) guard[tid] = 0u;
+    if (tid < 3) guard[tid] = 0u;
 
     // 1. spectrum of the zero-padded row at this thread's bins k = tid + j NB0 (first-pass register layout). Per bin two
     //    loads (utterance spectrum, channel table); the two phase factors follow from one load each: w_k = w_tid e^{-2 pi i
@@ -438,7 +477,11 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         yk[0] = {yk[0].re, yh.re};
     }
     float er[NBLK], ei[NBLK];
-    float pad_e, pad_o;
+    // 4. accuracy guard: block jj of this thread is the sample pair 2 (tid + NT jj), + 1. Inside [0, n) the row's maximum;
+    //    over the WHOLE padding region [n, M) the real part of a (the zero-padded row itself: zero in exact arithmetic,
+    //    while the imaginary part, the Hilbert transform of a time-limited signal, is not) - the error itself, including the
+    //    ringing-shaped part that starts at n. Block boundaries are wave-uniform: only blocks that hold padding pay for it.
+    float gin = 0.f, gout = 0.f;
     constexpr bool T0R = derive_tw0<float, LOG2H>();
     {
         // 2 + 3: both transforms' inputs formed at once - conj(A_e) / M and conj(A_o) / M =
@@ -455,26 +498,21 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         asm volatile("" : "+v"(tid_e), "+v"(v[0].re), "+v"(vo[PT - 1].im));
         fft_pass0_pair<LOG2H, NT, PT>(tw, tid_e, v, vo);
         fft_from_pass0<LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, v);
+        gout = pad_residual<R0, NT>(v, n, tid, 0, gout);
 #pragma unroll
         for (int j = 0; j < R0; ++j) {
             const cpx<float> a = v[brev<R0>(j)];
             er[j] = fsqrt(a.re * a.re + a.im * a.im);
         }
-        pad_e = fabsf(v[brev<R0>(R0 - 1)].re);
         fft_from_pass0<LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, vo);
         F2_SSTAMP(5);
+        gout = pad_residual<R0, NT>(vo, n, tid, 1, gout);
 #pragma unroll
         for (int j = 0; j < R0; ++j) {
             const cpx<float> a = vo[brev<R0>(j)];
             ei[j] = fsqrt(a.re * a.re + a.im * a.im);
         }
-        pad_o = fabsf(vo[brev<R0>(R0 - 1)].re);
     }
-    // 4. accuracy guard: block jj of this thread is the sample pair 2 (tid + NT jj), + 1. Inside [0, n) the row's
-    //    maximum; in the padding region the REAL part of a (the zero-padded row itself: zero in exact arithmetic, while
-    //    the imaginary part, the Hilbert transform of a time-limited signal, is not) - sampled in the last block, which
-    //    holds at least 64 padding samples of every row routed here.
-    float gin = 0.f, gout = 0.f;
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) {
         const int lo = 2 * NT * jj;
@@ -484,10 +522,6 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
             const int i0 = lo + 2 * tid;
             gin = fmaxf(gin, fmaxf(i0 < n ? er[jj] : 0.f, i0 + 1 < n ? ei[jj] : 0.f));
         }
-    }
-    {
-        const int i0 = 2 * (tid + NT * (NBLK - 1));
-        gout = fmaxf(i0 >= n ? pad_e : 0.f, i0 + 1 >= n ? pad_o : 0.f);
     }
     gin = wave_max63(gin);
     gout = wave_max63(gout);
@@ -501,14 +535,15 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         const __amdgpu_buffer_rsrc_t yb = row_buffer(y, n);
 #pragma unroll
         for (int jj = 0; jj < NBLK; ++jj) store_row_pair_buf(yb, n, 2 * (tid + NT * jj), (double)er[jj], (double)ei[jj]);
-        __syncthreads();
     } else {
-        lowpass_pairs_store_tab<NT, NBLK>(er, ei, P.lp, lptab, smem, y, n, tid);   // (contains barriers)
+        // the parity bar is written on the LOW-PASSED row (EnvelopeExtraction.py:57-66): its maximum, which a bursty row
+        // keeps several times below the raw one, is what the residual is compared with
+        float glp = lowpass_pairs_store_tab<NT, NBLK>(er, ei, P.lp, lptab, smem, y, n, tid);   // (contains barriers)
+        glp = wave_max63(glp);
+        if ((tid & 63) == 63) atomicMax(&guard[2], __float_as_uint(glp));
     }
-    if (tid == 0) {
-        const float gi = __uint_as_float(guard[0]), go = __uint_as_float(guard[1]);
-        if (go > P.tol * gi) P.uflag[b] = 1;
-    }
+    __syncthreads();
+    if (tid == 0) guard_decide(P, guard, b, c);
 #ifdef F2_STAMPS
     F2_SSTAMP(7);
     if (tid == 0 && P.stamps)
@@ -558,7 +593,7 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     constexpr int TWL = plan_tw_lds_count(LOG2Q);
     __shared__ __attribute__((aligned(16))) cpx<float> twl[TWL];
-    __shared__ unsigned guard[2];
+    __shared__ unsigned guard[3];
     __shared__ double ychain;
     cpx<float>* lds = reinterpret_cast<cpx<float>*>(smem);
 
@@ -583,7 +618,7 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
     const f2_f4* __restrict__ HUc = HUall + (size_t)c * P.tpitch;
 
     for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2Q, 1) + i];
-    if (tid < 2) guard[tid] = 0u;
+    if (tid < 3) guard[tid] = 0u;
     if (tid == 0) ychain = 0.0;
 
     const unsigned zstep = ((unsigned)NB0 * (unsigned)n) & (M - 1);
@@ -659,7 +694,7 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
                                                       F2_KSL_PARK_AUX);
 #endif
                 gin = fmaxf(gin, in ? e : 0.f);
-                if (j == R0 - 1) gout = fmaxf(gout, in ? 0.f : fabsf(a.re));
+                if (4 * NT * (j + 1) > n) gout = fmaxf(gout, in ? 0.f : fabsf(a.re));   // (wave-uniform: blocks that hold padding)
             }
         }
 #ifdef F2_STAMPS
@@ -683,6 +718,7 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
 #ifdef F2_KSL_KO_SWEEP   // knock-out (timing only)
     if (n < 0)
 #endif
+    float glp = 0.f;
 #pragma unroll 1
     for (int sw = 0; sw < 2; ++sw) {
         const int ibase = sw * 2 * NT * NBLK;
@@ -705,7 +741,7 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
         } else {
             const float e_in =   // sample 32767: the last of plane 3 of bank 0
                 sw ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yb, 4 * (park_plane(n, 0, 3) + 8191), 0, F2_KSL_PARK_AUX)) : 0.f;
-            lowpass_pairs_store_tab<NT, NBLK, true>(er, ei, P.lp, lptab, smem, y, n, tid, ibase, e_in, &ychain);
+            glp = fmaxf(glp, lowpass_pairs_store_tab<NT, NBLK, true>(er, ei, P.lp, lptab, smem, y, n, tid, ibase, e_in, &ychain));
         }
         __syncthreads();   // (the second sweep's inputs were parked before the first barrier above; `smem` is free again)
 #ifdef F2_STAMPS
@@ -713,10 +749,12 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
         else F2_SSTAMP(6);
 #endif
     }
-    if (tid == 0) {
-        const float gi = __uint_as_float(guard[0]), go = __uint_as_float(guard[1]);
-        if (go > P.tol * gi) P.uflag[b] = 1;
+    if (P.lpf) {
+        glp = wave_max63(glp);
+        if ((tid & 63) == 63) atomicMax(&guard[2], __float_as_uint(glp));
+        __syncthreads();
     }
+    if (tid == 0) guard_decide(P, guard, b, c);
 #ifdef F2_STAMPS
     F2_SSTAMP(7);
     if (tid == 0 && P.stamps)
@@ -1030,17 +1068,22 @@ int64_t ringing_length(double a1, double a2, double tol, int64_t limit) {
 }  // namespace
 
 // ---- host: eligibility, tables, launch ----
-bool f2_spectral_supports_len(int64_t n) {
+bool f2_spectral_supports_len(int64_t n, int min_pad) {
     if (n < 2) return false;
     const int log2h = f2_log2_ceil(n) - 1;
     if (log2h < F2_SPECTRAL_MIN_LOG2H || log2h > F2_SPECTRAL_MAX_LOG2H) return false;
-    return (int64_t(2) << log2h) - n >= 64;   // the accuracy guard needs padding samples to look at
+    // The accuracy guard reads the error off the padding samples [n, M). The part of it that is coherent across the bins -
+    // the float32 rounding of the ringing term's digits - is itself ringing-shaped: it starts at n, peaks 3 / -ln(r) samples
+    // later and wraps round into the START of the row. A row with less padding than that would hide the peak from the guard
+    // (tests/diag/guard_search.py: 1.3e-5 unflagged at 64 padding samples), so it keeps the two-kernel route.
+    return (int64_t(2) << log2h) - n >= std::max(64, min_pad);
 }
 
-bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::vector<int>* Lgroup) {
+bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::vector<int>* Lgroup, int* min_pad) {
     if (coefs.size() != (size_t)C * 10 || C <= 0) return false;
     const int groups = (C + 63) / 64;
     if (Lgroup) Lgroup->assign((size_t)groups, 0);
+    double peak = 0.0;
     for (int c = 0; c < C; ++c) {
         const double* k = &coefs[(size_t)c * 10];
         if (k[5] != 0.0 || k[0] == 0.0 || k[6] == 0.0 || k[9] == 0.0) return false;
@@ -1049,7 +1092,9 @@ bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::ve
         const int64_t L = ringing_length(k[7] / k[6], k[8] / k[6], 1e-8, int64_t(1) << 17);
         if (L <= 0) return false;
         if (Lgroup) (*Lgroup)[(size_t)c / 64] = std::max((*Lgroup)[(size_t)c / 64], (int)L);
+        peak = std::max(peak, 3.0 / (-0.5 * std::log(k[8] / k[6])));   // n^3 r^n peaks at n = 3 / -ln r
     }
+    if (min_pad) *min_pad = ((int)std::ceil(1.1 * peak) + 31) / 32 * 32;   // 256 for the 100 Hz channel of the reference's bank
     return true;
 }
 
@@ -1071,7 +1116,7 @@ static int spectral_tables(f2_ctx* ctx, const double* d_coefs, int C, int log2h,
     t.C = C;
     t.coefs = ctx->coefs_host;
     std::vector<int> Lg;
-    if (!f2_spectral_supports_coefs(t.coefs, C, &Lg)) return f2_fail(ctx, F2_ERR_INVALID, "coefficient table not eligible");
+    if (!f2_spectral_supports_coefs(t.coefs, C, &Lg, nullptr)) return f2_fail(ctx, F2_ERR_INVALID, "coefficient table not eligible");
     const int H = 1 << log2h, M = 2 * H;
     t.tpitch = H + 8;
     F2_TRY(f2_reserve(ctx, t.hu, sizeof(float) * 4 * (size_t)C * (size_t)t.tpitch));
@@ -1166,6 +1211,7 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
     const f2_f4* d_lptab = nullptr;
     F2_TRY(lowpass_table(ctx, a1, b0, threads_for<float, FFTLOG>(), 2, &P.lp, &d_lptab));
     P.tol = tol;
+    P.gdump = ctx->opt_spectral_guard_dump ? (float*)ctx->spec_gdump.ptr : nullptr;
     P.stamps = nullptr;
 #ifdef F2_STAMPS
     static unsigned long long* d_stamps = nullptr;

@@ -100,21 +100,36 @@ def _kfd_order_known(sysfs):
     return os.path.isdir(os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes"))
 
 
-def pin_to_gpu_numa_node(local=None, sysfs="/sys", apply=True):
+def _render_nodes(dev):
+    """number of DRM render nodes this process can see (/dev/dri/renderD*), or None if the directory cannot be read"""
+    try:
+        return sum(1 for n in os.listdir(os.path.join(dev, "dri")) if n.startswith("renderD"))
+    except OSError:
+        return None
+
+
+def pin_to_gpu_numa_node(local=None, sysfs="/sys", apply=True, dev="/dev"):
     """Restrict this process to the cores of the NUMA node its GPU hangs off, BEFORE the first GPU call: the staging
     buffers it then allocates (first touch) and its reader / writer threads stay next to the device's PCIe root. With
     eight ranks on a two-socket host the alternative is that half of them copy across the socket link.
     `local` = index among the visible GPUs (default: local_device()); ROCR_VISIBLE_DEVICES filters the runtime's list first
     and HIP_VISIBLE_DEVICES then indexes what is left - both are applied, in that order, when they list plain indices.
     Returns {"gpu", "numa_node", "cpus"} or None - and changes nothing - whenever the answer is not certain: no sysfs entry,
-    a visibility variable that is not a list of indices (UUIDs), an index out of range, affinity calls unavailable, or an
+    a visibility variable that is not a list of indices (UUIDs), an index out of range, affinity calls unavailable, an
     enumeration order that had to be guessed from PCI addresses while the GPUs sit on different nodes (a wrong guess would
-    pin the rank to the far socket, the copies this function exists to avoid)."""
+    pin the rank to the far socket, the copies this function exists to avoid), CUDA_VISIBLE_DEVICES / GPU_DEVICE_ORDINAL
+    set (HIP honours them too, with rules of their own), or a container whose device cgroup hides some of the GPUs the KFD
+    topology lists (fewer /dev/dri/renderD* nodes than KFD GPU nodes: the runtime skips the hidden ones, the sysfs tree
+    still counts them - round-4 advisor finding)."""
     if not hasattr(os, "sched_setaffinity"):
+        return None
+    if os.environ.get("CUDA_VISIBLE_DEVICES") or os.environ.get("GPU_DEVICE_ORDINAL"):
         return None
     local = local_device() if local is None else int(local)
     gpus = gpu_numa_nodes(sysfs)
     if not _kfd_order_known(sysfs) and len({node for _, node in gpus}) > 1:
+        return None
+    if _kfd_order_known(sysfs) and len({node for _, node in gpus}) > 1 and _render_nodes(dev) != len(gpus):
         return None
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
         visible = os.environ.get(var)

@@ -100,27 +100,56 @@ def GenerateInputData(labelFile=None, inputFile=None, LPF=False, CUTOFF=100):
 
 def _run_token():
     """What tells this launch's marker files from those a dead earlier launch left behind. $F2CNN_RUN_ID when the launcher
-    exports one (ranks started by hand, in separate shells, must: they share nothing else). Otherwise torchrun's
-    $TORCHELASTIC_RUN_ID (the literal 'none' unless --rdzv-id is given) or $MASTER_PORT - the same on every launch - TOGETHER
-    WITH THE PARENT'S PID: the ranks of one single-node launch are children of one launcher process, and a relaunch after a
-    crash has another (round-3 advisor finding: a rank that met the dead launch's `ready` marker mapped the old file, which
-    rank 0 then replaced)."""
+    exports one (ranks started by hand, in separate shells or on several nodes, should: they share nothing else).
+    Otherwise torchrun's $TORCHELASTIC_RUN_ID (the literal 'none' unless --rdzv-id is given) or $MASTER_PORT - the same on
+    every node of a launch, but also on every RE-launch. The parent's PID is added only where it provably is common to all
+    ranks: a single-node launch ($LOCAL_WORLD_SIZE == $WORLD_SIZE) whose ranks are direct children of one launcher
+    (torchrun / `bench.py --gpus N` style). Ranks on several nodes, or behind per-rank wrapper shells, have different
+    parents (round-4 advisor finding: they then waited 600 s for a marker that could not come) and fall back to the
+    launcher id alone; what protects THEM from a dead launch's leftovers is the marker's content (`_shared_output`)."""
     v = os.environ.get("F2CNN_RUN_ID")
     if v:
         return "".join(ch if ch.isalnum() else "_" for ch in v)
     base = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT") or "0"
-    return "".join(ch if ch.isalnum() else "_" for ch in base) + "_p{}".format(os.getppid())
+    token = "".join(ch if ch.isalnum() else "_" for ch in base)
+    lws, ws = os.environ.get("LOCAL_WORLD_SIZE"), os.environ.get("WORLD_SIZE")
+    if lws is not None and lws == ws and os.environ.get("F2CNN_RANKS_SHARE_PARENT", "1") != "0":
+        token += "_p{}".format(os.getppid())
+    return token
 
 
 def _marker(target, what, rank):
     return "{}.{}.{}.rank{}".format(target, what, _run_token(), rank)
 
 
+def _foreign_marker(target, what, rank, newer_than):
+    """A fresh marker of the same kind and rank under ANOTHER token: the ranks of this launch disagree about the token."""
+    import glob
+    mine = _marker(target, what, rank)
+    for path in glob.glob("{}.{}.*.rank{}".format(glob.escape(target), what, rank)):
+        try:
+            if path != mine and os.path.getmtime(path) >= newer_than:
+                return path
+        except OSError:
+            pass
+    return None
+
+
+STALE_WINDOW = 120.0     # seconds a rank may start after rank 0 announced the file (launch skew + clock skew across nodes)
+FOREIGN_WINDOW = 5.0     # a marker under ANOTHER token this close to (or after) a rank's own start belongs to its own launch
+_SEEN_NONCE = {}         # target -> nonce of the `ready` marker this process mapped the file under
+
+
 def _shared_output(target, shape, rank, world, timeout=600.0):
     """The pre-sized output .npy all ranks write into (numpy.lib.format.open_memmap). Rank 0 creates it - under a
     temporary name, renamed into place once its header is written - and announces it with a marker that carries this
-    launch's token and the shape; the others wait for exactly that marker (the ranks of a file command share nothing
-    but the file system). Every rank removes only its OWN markers of an earlier launch with the same token."""
+    launch's token and, as its content, the shape, a nonce, rank 0's start time and the identity (inode, size) of the file it
+    created; the others wait for exactly that marker (the ranks of a file command share nothing but the file system),
+    accept it only if it is not older than their own start minus STALE_WINDOW, and after mapping the file check that it
+    still IS the file the marker describes (a leftover marker of a dead launch with the same token describes a file that
+    rank 0 has since replaced). Every rank removes only its OWN markers of an earlier launch with the same token."""
+    import json
+    started = time.time()
     for what in ("ready", "done"):
         if os.path.exists(_marker(target, what, rank)):
             os.remove(_marker(target, what, rank))
@@ -130,36 +159,75 @@ def _shared_output(target, shape, rank, world, timeout=600.0):
         del out
         os.replace(tmp, target)
         out = numpy.lib.format.open_memmap(target, mode='r+')
-        with open(_marker(target, "ready", 0), "w") as f:
-            f.write(repr(tuple(shape)))
-        return out
-    deadline = time.time() + timeout
-    started = time.time()
-    while True:
+        st = os.stat(target)
         mk = _marker(target, "ready", 0)
+        with open(mk + ".tmp", "w") as f:
+            json.dump({"shape": list(shape), "nonce": "{}-{}".format(os.getpid(), time.time_ns()), "started": started,
+                       "inode": st.st_ino, "size": st.st_size}, f)
+        os.replace(mk + ".tmp", mk)
+        return out
+    deadline = started + timeout
+    mk = _marker(target, "ready", 0)
+    while True:
+        info = None
         try:
-            # a marker of this token that predates this rank by more than a day is a leftover, not an announcement
-            if os.path.getmtime(mk) >= started - 86400 and open(mk).read() == repr(tuple(shape)):
-                break
-        except OSError:
-            pass
+            if os.path.getmtime(mk) >= started - STALE_WINDOW:
+                with open(mk) as f:
+                    info = json.load(f)
+        except (OSError, ValueError):
+            info = None
+        if info is not None and tuple(info.get("shape", ())) == tuple(shape):
+            try:
+                out = numpy.lib.format.open_memmap(target, mode='r+')
+                st = os.stat(target)
+            except (OSError, ValueError):
+                out = None
+            if out is not None and st.st_ino == info.get("inode") and st.st_size == info.get("size"):
+                _SEEN_NONCE[os.path.abspath(target)] = info.get("nonce")
+                break                       # the file on disk is the one this marker announced
+            del out                         # rank 0 is replacing it right now (or the marker is a leftover): look again
+        other = _foreign_marker(target, "ready", 0, started - FOREIGN_WINDOW)
+        if other:
+            raise RuntimeError("{} was announced as {} while rank {} expects token {!r}: the ranks of this launch do not "
+                               "share a launch token - export F2CNN_RUN_ID=<same value> on every rank (or another launch "
+                               "is writing the same file / died seconds ago: remove its marker)"
+                               .format(target, os.path.basename(other), rank, _run_token()))
         if time.time() > deadline:
-            raise TimeoutError("rank 0 did not create {} (token {})".format(target, _run_token()))
+            raise TimeoutError("rank 0 did not create {} (token {!r}; export F2CNN_RUN_ID=<same value> on every rank if the "
+                               "ranks were not started by one launcher)".format(target, _run_token()))
         time.sleep(0.05)
-    out = numpy.lib.format.open_memmap(target, mode='r+')
     if out.shape != shape or out.dtype != numpy.float32:
         raise ValueError("{} has shape {} / dtype {}, expected {} float32".format(target, out.shape, out.dtype, shape))
     return out
 
 
 def _finish_shared_output(target, backup, rank, world, timeout=3600.0):
+    if rank != 0:
+        # the file this rank wrote into must still be the one rank 0 announced: a leftover `ready` marker of a dead launch
+        # with the same token can be met before rank 0 of THIS launch has replaced it - then the rows written are gone
+        import json
+        try:
+            with open(_marker(target, "ready", 0)) as f:
+                nonce = json.load(f).get("nonce")
+        except (OSError, ValueError):
+            nonce = None
+        if nonce != _SEEN_NONCE.get(os.path.abspath(target)):
+            raise RuntimeError("rank 0 replaced {} after rank {} had mapped it (a marker left by an earlier launch with the "
+                               "same token {!r}): this rank's rows are lost - rerun with F2CNN_RUN_ID=<fresh value> on "
+                               "every rank".format(target, rank, _run_token()))
     open(_marker(target, "done", rank), "w").close()
     if rank != 0:
         return
-    deadline = time.time() + timeout
+    began = time.time()
+    deadline = began + timeout
     while not all(os.path.exists(_marker(target, "done", r)) for r in range(world)):
+        for r in range(1, world):
+            other = None if os.path.exists(_marker(target, "done", r)) else _foreign_marker(target, "done", r, began - FOREIGN_WINDOW)
+            if other:
+                raise RuntimeError("rank {} reported {} but rank 0 expects token {!r}: export F2CNN_RUN_ID=<same value> on "
+                                   "every rank".format(r, os.path.basename(other), _run_token()))
         if time.time() > deadline:
-            raise TimeoutError("not every rank finished its part of {}".format(target))
+            raise TimeoutError("not every rank finished its part of {} (token {!r})".format(target, _run_token()))
         time.sleep(0.05)
     import shutil
     if os.path.abspath(backup) != os.path.abspath(target):

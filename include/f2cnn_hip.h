@@ -60,7 +60,7 @@ enum { F2_WAVE_I16 = 0, F2_WAVE_F64 = 1 };
 enum { F2_FFT_F32 = 0, F2_FFT_F64 = 1 };
 
 /* ---- library / context -------------------------------------------------------------------- */
-int f2_version(void);   /* 100 * major + minor; 101 added f2_eval_batch, 102 f2_host_alloc + F2_MEM_HOST_ASYNC, 103 f2_ctx_set_option */
+int f2_version(void);   /* 100 * major + minor; 101 added f2_eval_batch, 102 f2_host_alloc + F2_MEM_HOST_ASYNC, 103 f2_ctx_set_option, 105 f2_spectral_guard_read + f2_cnn_get_info */
 int f2_device_count(int* count);
 int f2_ctx_create(int device, f2_ctx** ctx);
 int f2_ctx_destroy(f2_ctx* ctx);
@@ -76,7 +76,12 @@ const char* f2_last_error(f2_ctx* ctx);
  *                                      spectral path; 0 = always filterbank kernel + envelope kernel
  *   "spectral_min_rows"  rows (utterances x channels) a call needs before that path is used (default 4096: below,
  *                        the serial filter-state kernel is not hidden and the time-split filterbank kernel is faster)
- *   "spectral_tol"   accuracy guard of that path (default 4e-6): relative residual that sends an utterance back
+ *   "spectral_tol"   accuracy guard of that path (default 4e-6): padding-region residual, relative to the maximum of the row as
+ *                    delivered (the low-passed row when lpf != 0), that sends an utterance back
+ *   "spectral_min_pad"  zero-padding samples (2^k - n) a row needs for that path: -1 (default) = what the slowest channel's
+ *                    ringing needs to reach its peak, from the coefficient table (256 for the reference's 100 Hz .. 8 kHz
+ *                    bank), so that the guard sees the error it has to judge; an explicit value >= 64 for experiments
+ *   "spectral_guard_dump"  1 / 0 (default)   keep the guard's per-row values (f2_spectral_guard_read)
  *   "k1_split"       -1 / 0 / K >= 2   time-split filterbank for small batches: auto / never / K segments
  *   "k1_queue"       -1 / 0 / 1        unit queue of the filterbank for ragged batches
  *   "k1_qwaves"      0 / n             waves of the queue launch (0 = from the batch)
@@ -99,6 +104,12 @@ const char* f2_last_error(f2_ctx* ctx);
  * Two contexts on two host threads choose independently. */
 int f2_ctx_set_option(f2_ctx* ctx, const char* key, double value);
 int f2_ctx_get_option(f2_ctx* ctx, const char* key, double* value);
+/* Diagnostic of the spectral path's accuracy guard (no reference counterpart; used by tests/diag/guard_search.py). With
+ * option "spectral_guard_dump" = 1 the last f2_filterbank_envelope_fused call that took the spectral route keeps, per
+ * (utterance b, channel c) row in batch order, four floats {maximum of |analytic signal| inside the row, maximum of the
+ * padding-region residual, maximum of the low-passed row (0 without low-pass), 1 if this row tripped the guard}; rows the
+ * spectral kernel did not serve read as NaN. Copies min(rows, available) rows to `out` (host) and waits for the stream. */
+int f2_spectral_guard_read(f2_ctx* ctx, float* out, int64_t rows, int64_t* rows_available);
 
 /* ---- device memory + timing helpers (so a host language needs no HIP binding of its own) ---- */
 int f2_dev_malloc(f2_ctx* ctx, size_t bytes, void** dptr);
@@ -187,6 +198,13 @@ int f2_gather_windows(f2_ctx* ctx, const double* env, int C, int64_t N, const in
  */
 int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channels, f2_cnn** cnn);
 int f2_cnn_destroy(f2_ctx* ctx, f2_cnn* cnn);
+/* What f2_cnn_create found out about this network (no reference counterpart). Keys: "flat" (flatten size); "ws_ok" /
+ * "ws_dense_ok" = 1 if the weight-stationary convolution / dense1 kernels (option "cnn_ws" / "cnn_ws_dense") serve this
+ * network: its shape qualifies AND they reproduced the per-tile kernels' scores on f2_cnn_create's self-check batch (their
+ * hand-placed memory waits are only valid for the register allocation of the compiler they were validated with; a library
+ * built by another hipcc that fails the check falls back to the per-tile kernels and says so on stderr);
+ * "ws_check_diff" / "ws_dense_check_diff" = the score differences measured (-1: not applicable). */
+int f2_cnn_get_info(f2_ctx* ctx, const f2_cnn* cnn, const char* key, double* value);
 int f2_cnn_forward(f2_ctx* ctx, const f2_cnn* cnn, const float* x, int64_t n, float* scores,
                    uint8_t* labels, int mem_space);
 

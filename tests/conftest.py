@@ -19,6 +19,12 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "f2cnn_golden.npz"))
 
 
+@pytest.fixture(scope="session")
+def golden_eval():
+    """G5: the tensor the reference hands to model.predict for one 1 s file (tests/golden/make_golden.py eval)"""
+    return np.load(os.path.join(ROOT, "tests", "golden", "f2cnn_golden_eval.npz"))
+
+
 def chan_relerr(a, b):
     """Parity norm of SURVEY section 8d: per-channel max|a-b| / max|b| (rows = channels)."""
     a = np.asarray(a, dtype=np.float64)

@@ -5,13 +5,21 @@ Generate the golden vectors under tests/golden/ by IMPORTING the reference (read
 reference source is copied. The reference does not exist on the GPU box, so the .npz files are
 committed and this script documents how they were made.
 
-    python tests/golden/make_golden.py          # needs /root/reference
+    python tests/golden/make_golden.py          # needs /root/reference; writes f2cnn_golden.npz (G1-G4, G6)
+    python tests/golden/make_golden.py eval     # writes f2cnn_golden_eval.npz (G5) only
 
 Imports used (all import cleanly here): gammatone.filters,
 scripts.processing.EnvelopeExtraction, scripts.processing.InputGenerator, scripts.CNN.Training
-(normalizeInput only). scripts.CNN.Evaluating / scripts.processing.GammatoneFiltering need the absent
-`sphfile`/`keras` packages and are NOT imported (no stand-ins are written); the `cnn eval` window
-tensor is therefore pinned through its parts (normalizeInput + the gather formula).
+(normalizeInput only).
+
+G5: scripts.CNN.Evaluating imports `sphfile` (through GammatoneFiltering.py:21) and `keras`
+(Evaluating.py:84), neither of which exists in this image. Two stand-in MODULES are written into a scratch directory
+(never into the repo): `sphfile.py` whose SPHFile refuses to be used (the RIFF branch of GetArrayFromWAV never reaches it)
+and a `keras` package whose `models.load_model(...).predict(x)` stores x and stops the run. Nothing of the reference
+executes differently before that point: its unmodified EvaluateOneWavFile reads the RIFF file, filters, extracts the
+envelopes, gathers and normalises every window and calls predict (Evaluating.py:42-86) - the tensor it hands over is
+the fixture. (The stand-ins replace the absent third-party packages, not reference code; the CNN arithmetic itself stays
+unpinned - there is no Keras to run.)
 """
 import contextlib
 import io
@@ -127,5 +135,67 @@ def main():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB;", len(out), "arrays")
 
 
+def g5_eval_tensor():
+    """The (nb, 11, 128, 1) float64 tensor at the reference's `predict` call for one 1 s RIFF file, LPF off and 50 Hz."""
+    import hashlib
+    import importlib
+    from scipy.io import wavfile
+    out = {}
+    wave = noise(2028, 16000)          # utterance 0 of BASELINE cfg4 (seed 2028)
+    out["g5_wave"] = wave
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        stubs = os.path.join(tmp, "absent_packages")
+        os.makedirs(os.path.join(stubs, "keras"))
+        with open(os.path.join(stubs, "sphfile.py"), "w") as f:
+            f.write("class SPHFile:\n    def __init__(self, *a, **k):\n        raise RuntimeError('sphfile is not installed')\n")
+        with open(os.path.join(stubs, "keras", "__init__.py"), "w") as f:
+            f.write("from . import models, backend\n")
+        with open(os.path.join(stubs, "keras", "backend.py"), "w") as f:
+            f.write("def clear_session():\n    pass\n")
+        with open(os.path.join(stubs, "keras", "models.py"), "w") as f:
+            f.write("import numpy\n\n\nclass Reached(Exception):\n    pass\n\n\nclass _Recorder:\n"
+                    "    def __init__(self, path):\n        self.path = path\n\n"
+                    "    def predict(self, x, verbose=0):\n        numpy.save('predict_argument.npy', x)\n"
+                    "        raise Reached(self.path)\n\n\ndef load_model(path):\n    return _Recorder(path)\n")
+        sys.path.insert(0, stubs)
+        os.environ["MPLBACKEND"] = "Agg"
+        os.chdir(tmp)
+        try:
+            with open("configF2CNN.conf", "w") as f:
+                f.write("[FILTERBANK]\nframerate = 16000\nnchannels = 128\nlow_freq = 100\n\n"
+                        "[CNN]\nformant = 2\ncentered = True\nradius = 5\nbatch_size = 32\nepochs = 20\n"
+                        "risk = 0.05\nsampling_period = 10000\n")
+            os.makedirs("resources/f2cnn/TEST")
+            wav = "resources/f2cnn/TEST/DR1.FXYZ0.SA1.WAV"
+            wavfile.write(wav, 16000, wave)
+            ref_eval = importlib.import_module("scripts.CNN.Evaluating")
+            reached = importlib.import_module("keras.models").Reached
+            for tag, lpf in (("nolpf", False), ("lpf50", True)):
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        ref_eval.EvaluateOneWavFile(wav, LPF=lpf, CUTOFF=50, model="last_trained_model")
+                    raise AssertionError("predict was not reached")
+                except reached:
+                    pass
+                x = np.load("predict_argument.npy")
+                os.remove("predict_argument.npy")
+                assert x.shape == (16000 - 11 * 160, 11, 128, 1) and x.dtype == np.float64, (x.shape, x.dtype)
+                nb = x.shape[0]
+                out[f"g5_{tag}_windows"] = x[[0, 1, 7000, nb - 1]]
+                out[f"g5_{tag}_window_sums"] = x.reshape(nb, -1).sum(axis=1)
+                out[f"g5_{tag}_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest())
+                out[f"g5_{tag}_shape"] = np.array(x.shape)
+        finally:
+            os.chdir(cwd)
+            sys.path.remove(stubs)
+    path = os.path.join(HERE, "f2cnn_golden_eval.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB;", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["eval"]:
+        g5_eval_tensor()
+    else:
+        main()

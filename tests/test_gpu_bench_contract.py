@@ -119,18 +119,26 @@ def test_device_pointer_calls_only_enqueue_even_for_a_new_batch_shape():
         ctx.filterbank_envelope_fused(d_wave, _lib.WAVE_I16, off_a, coefs, len(lens_a), C, True, 50.0, _lib.FFT_F32, d_env, None,
                                       _lib.MEM_DEVICE)
         ctx.synchronize()
+        # The causal property only (round-4 advisor finding: a wall-clock bound on host time against device time fails on a
+        # loaded host with nothing wrong): right after the call returns, the event recorded behind it has not been reached.
+        # One retry with the two shapes swapped, in case the host thread was descheduled between the call and the query.
         ev = ctx.event()
-        t0 = time.perf_counter()
-        ctx.filterbank_envelope_fused(d_wave, _lib.WAVE_I16, off_b, coefs, len(lens_b), C, True, 50.0, _lib.FFT_F32, d_env, None,
-                                      _lib.MEM_DEVICE)
-        ctx.record(ev)
-        t_call = time.perf_counter() - t0
-        still_running = not ctx.event_done(ev)
-        ctx.synchronize()
-        t_all = time.perf_counter() - t0
-        assert ctx.event_done(ev)
-        print(f"call returned after {t_call * 1e3:.2f} ms, device finished after {t_all * 1e3:.2f} ms")
-        assert still_running and t_call < 0.5 * t_all, (t_call, t_all)
+        still_running = False
+        for off, lens in ((off_b, lens_b), (off_a, lens_a), (off_b, lens_b)):
+            t0 = time.perf_counter()
+            ctx.filterbank_envelope_fused(d_wave, _lib.WAVE_I16, off, coefs, len(lens), C, True, 50.0, _lib.FFT_F32, d_env, None,
+                                          _lib.MEM_DEVICE)
+            ctx.record(ev)
+            t_call = time.perf_counter() - t0
+            still_running = not ctx.event_done(ev)
+            ctx.synchronize()
+            t_all = time.perf_counter() - t0
+            assert ctx.event_done(ev)
+            print(f"call returned after {t_call * 1e3:.2f} ms, device finished after {t_all * 1e3:.2f} ms "
+                  f"(ratio {t_call / t_all:.2f}), event pending at return: {still_running}")
+            if still_running and off is off_b:
+                break
+        assert still_running
         # and the new shape's results are those of its utterances (spot check: first, a long one, last)
         for b in (0, int(np.argmax(lens_b)), len(lens_b) - 1):
             n = int(lens_b[b])

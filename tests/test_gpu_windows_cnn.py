@@ -68,6 +68,32 @@ def test_eval_windows_normalised():
     assert out.min() == 0.0 and out.max() == 1.0
 
 
+@pytest.mark.parametrize("tag,lpf", [("nolpf", False), ("lpf50", True)])
+def test_eval_windows_match_the_reference_predict_argument(golden_eval, tag, lpf):
+    """G5 (the tensor at the reference's model.predict call, Evaluating.py:71-86): f2_gather_windows(centers = NULL,
+    normalize = 1) on envelopes that are within 1e-13 of the reference's own (the oracle chain, pinned by G2 / G3), and
+    the windows the device pipeline builds from the samples (filterbank kernel + envelope kernel, float64 FFT)."""
+    ctx = _lib.default_context()
+    wave = golden_eval["g5_wave"]
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    nb = int(golden_eval[f"g5_{tag}_shape"][0])
+    sel = [0, 1, 7000, nb - 1]
+    want = golden_eval[f"g5_{tag}_windows"][..., 0]
+    sums = golden_eval[f"g5_{tag}_window_sums"]
+    env = orc.filter_and_envelope(wave, coefs, lpf, 50)
+    out = np.empty((nb, 11, 128), np.float32)
+    ctx.gather_windows(env, 128, 16000, None, nb, 5, 160, True, out, _lib.MEM_HOST)
+    np.testing.assert_allclose(out[sel], want, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out.reshape(nb, -1).astype(np.float64).sum(axis=1), sums, rtol=1e-6)
+    # the same from the device's own envelopes
+    env_d = np.empty(128 * 16000)
+    ctx.filterbank_envelope_fused(wave, _lib.WAVE_I16, np.array([0, 16000], np.int64), coefs, 1, 128, lpf, 50.0, _lib.FFT_F64,
+                                  env_d, None, _lib.MEM_HOST)
+    ctx.gather_windows(env_d.reshape(128, 16000), 128, 16000, None, nb, 5, 160, True, out, _lib.MEM_HOST)
+    np.testing.assert_allclose(out[sel], want, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out.reshape(nb, -1).astype(np.float64).sum(axis=1), sums, rtol=1e-6)
+
+
 @pytest.mark.parametrize("rows,channels,n", [(11, 128, 257), (11, 64, 40), (13, 40, 33), (10, 100, 19), (11, 190, 9)])
 def test_cnn_forward_vs_oracle(rows, channels, n):
     m = F2CNNModel.glorot(7, rows, channels, zero_bias=False)

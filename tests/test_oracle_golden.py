@@ -126,6 +126,20 @@ def test_gather_windows_matches_reference(golden):
     assert int(golden["g4_last_input_equal"]) == 1
 
 
+@pytest.mark.parametrize("tag,lpf", [("nolpf", False), ("lpf50", True)])
+def test_eval_tensor_matches_the_reference_predict_argument(golden_eval, tag, lpf):
+    """G5: what the reference's unmodified EvaluateOneWavFile hands to model.predict (Evaluating.py:42-86) for one 1 s RIFF
+    file - filterbank, envelope, every-sample gather, per-window normalizeInput, reshape - against the oracle chain from
+    the same samples. Four whole windows and the sum of every one of the 14 240 windows."""
+    wave = golden_eval["g5_wave"]
+    coefs = orc.make_erb_filters(16000, orc.centre_freqs(16000, 128, 100))
+    x = orc.eval_input_tensor(orc.filter_and_envelope(wave, coefs, lpf, 50))
+    assert x.dtype == np.float64 and list(x.shape) == list(golden_eval[f"g5_{tag}_shape"])
+    nb = x.shape[0]
+    np.testing.assert_allclose(x[[0, 1, 7000, nb - 1]], golden_eval[f"g5_{tag}_windows"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(x.reshape(nb, -1).sum(axis=1), golden_eval[f"g5_{tag}_window_sums"], rtol=1e-12)
+
+
 def test_eval_tensor_shape_and_range():
     # KAT 6 (restated; the reference's Evaluating.py cannot be imported here, see make_golden.py)
     env = np.random.default_rng(0).random((16, 2000)) + 0.5
