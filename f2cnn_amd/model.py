@@ -1,9 +1,14 @@
 """Weight container for the F2CNN network (architecture: reference scripts/CNN/Training.py:93-114).
 
-The reference stores a Keras HDF5 model (``last_trained_model``, Training.py:139); neither Keras nor h5py
-exists here, so weights travel as an ``.npz`` holding the 12 tensors in their Keras layouts:
+The reference stores a Keras HDF5 model (``last_trained_model``, Training.py:139). Here weights travel as an ``.npz``
+holding the 12 tensors in their Keras layouts:
 
     conv{1..4}_w (3,3,Cin,Cout)  conv{1..4}_b (Cout,)  dense1_w (F,516) dense1_b  dense2_w (516,2) dense2_b
+
+A genuine Keras ``last_trained_model`` (HDF5) is read through h5py where that package exists (``F2CNNModel.load``
+recognises the HDF5 signature; ``python -m f2cnn_amd.model last_trained_model out.npz`` converts once, on the machine
+that trained the model). h5py is not part of this image, so the reader is exercised against a stand-in that mimics
+h5py's File / Group / Dataset interface (tests/test_host_io_cli.py), not against a file Keras wrote.
 
 A PyTorch ``state_dict`` (Conv2d OIHW / Linear (out,in), NCHW flatten) is converted by
 ``F2CNNModel.from_torch_state_dict``. The forward pass itself is HIP kernel K4 (``f2_cnn_forward``).
@@ -65,9 +70,46 @@ class F2CNNModel:
         return cls(t, rows, channels)
 
     @classmethod
-    def load(cls, path):
+    def from_keras_hdf5(cls, path, rows=11, channels=128):
+        """Weights of a model saved by the reference (keras model.save / save_weights, Training.py:139): HDF5 group
+        `model_weights` (or the file root for save_weights), attribute `layer_names`, per layer `weight_names`
+        ('<layer>/kernel:0', '<layer>/bias:0'). The six layers that carry weights - Conv2D x 4, Dense x 2, in model order -
+        are taken in order whatever their names; Keras stores exactly the layouts this container uses."""
+        try:
+            import h5py
+        except ImportError as exc:
+            raise ImportError(f"{path} is a Keras HDF5 model; reading it needs h5py, which is not installed here. Convert it "
+                              "once where it is: python -m f2cnn_amd.model {0} {0}.npz".format(path)) from exc
+
+        def text(v):
+            return v.decode() if isinstance(v, bytes) else str(v)
+        with h5py.File(path, "r") as f:
+            g = f["model_weights"] if "model_weights" in f else f
+            pairs = []
+            for lname in [text(v) for v in g.attrs["layer_names"]]:
+                names = [text(v) for v in g[lname].attrs.get("weight_names", [])]
+                if not names:
+                    continue                                   # pooling / dropout / flatten layers
+                kern = [n for n in names if n.split("/")[-1].startswith("kernel")]
+                bias = [n for n in names if n.split("/")[-1].startswith("bias")]
+                if len(kern) != 1 or len(bias) != 1:
+                    raise ValueError(f"layer {lname}: expected one kernel and one bias, found {names}")
+                pairs.append((np.asarray(g[lname][kern[0]]), np.asarray(g[lname][bias[0]])))
+        if len(pairs) != len(NAMES):
+            raise ValueError(f"{path}: {len(pairs)} layers with weights, the F2CNN network has {len(NAMES)}")
+        t = {}
+        for name, (k, b) in zip(NAMES, pairs):
+            t[name + "_w"], t[name + "_b"] = k, b
+        return cls(t, rows, channels)
+
+    @classmethod
+    def load(cls, path, rows=11, channels=128):
         if not os.path.exists(path) and os.path.exists(str(path) + ".npz"):
             path = str(path) + ".npz"
+        with open(path, "rb") as fp:
+            magic = fp.read(8)
+        if magic == b"\x89HDF\r\n\x1a\n":
+            return cls.from_keras_hdf5(path, rows, channels)
         z = np.load(path)
         rows = int(z["rows"]) if "rows" in z else 11
         channels = int(z["channels"]) if "channels" in z else 128
@@ -130,5 +172,14 @@ class F2CNNModel:
 
 
 def load_model(path):
-    """Counterpart of keras.models.load_model for the .npz container."""
+    """Counterpart of keras.models.load_model: the .npz container, or a Keras HDF5 file where h5py is installed."""
     return F2CNNModel.load(path)
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) != 3:
+        raise SystemExit("usage: python -m f2cnn_amd.model <keras last_trained_model (HDF5)> <out.npz>")
+    m = F2CNNModel.from_keras_hdf5(sys.argv[1])
+    m.save(sys.argv[2])
+    print("wrote", sys.argv[2], {k: v.shape for k, v in m.tensors.items()})

@@ -35,11 +35,12 @@ def test_ragged_batch_against_oracle_and_two_kernel_route(lpf):
     """Lengths on the four length classes the kernels serve (4097..8192, 8193..16384, 16385..32768 samples: the last one
     transforms its utterances decimated by two; 32769..65472: four 16384-point transforms per row, utterances decimated
     by four), odd lengths, the shortest padding they accept (64 samples), and lengths they leave to the two-kernel route
-    (fewer padding samples, short and longer rows) in one batch; 128 channels."""
+    (fewer padding samples than the slowest channel's ringing needs to peak - 256 for this bank -, short and longer rows) in
+    one batch; 128 channels."""
     ctx = _lib.default_context()
     coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
     lens = [16000, 15999, 9000, 8193, 16320, 16321, 4097, 5000, 8128, 8129, 300, 16384, 20000, 1, 32704, 32705, 16385,
-            27001, 40000, 32769, 65472, 65473, 50001, 65536, 33333, 70000]
+            27001, 40000, 32769, 65472, 65473, 50001, 65536, 33333, 70000, 16128, 16129, 7936, 7937, 32512, 32513, 65280, 65281]
     waves = [orc.synth_utterance(500 + i, n) for i, n in enumerate(lens)]
     got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
     old, _ = fused(ctx, waves, coefs, lpf, spectral=0)
@@ -60,11 +61,39 @@ def test_long_class_boundaries():
     lens = [32769, 32770, 32771, 32772, 32773, 36863, 36864, 36865, 61439, 61440, 61441, 65469, 65470, 65471, 65472]
     waves = [orc.synth_utterance(900 + i, n) for i, n in enumerate(lens)]
     for lpf in (False, True):
-        got, flagged = fused(ctx, waves, coefs, lpf, spectral=1)
+        # (spectral_min_pad = 64: the kernel itself serves rows up to 65472 samples; the default eligibility rule keeps
+        # rows with fewer than 256 padding samples off this route for the accuracy guard's sake)
+        got, flagged = fused(ctx, waves, coefs, lpf, spectral=1, spectral_min_pad=64)
+        assert int(ctx.get_option("spectral_routed")) == len(lens)
         assert flagged == 0
         for w, g in zip(waves, got):
             assert not np.isnan(g).any()
             assert chan_relerr(g, orc.filter_and_envelope(w, coefs, lpf, 50)) <= TOL, len(w)
+
+
+def test_rows_with_little_padding_keep_the_two_kernel_route():
+    """The accuracy guard judges a row by the padding samples [n, 2^k). The coherent part of the error (the float32 digits of the
+    ringing term) is ringing-shaped: it starts at n, peaks 3 / -ln(pole radius) samples later (211 for the 100 Hz channel) and
+    wraps round into the START of the row - with fewer padding samples than that the guard cannot see its peak
+    (tests/diag/guard_search.py at spectral_min_pad = 64: 1.3e-5 unflagged). Such rows are not routed to the spectral kernel."""
+    ctx = _lib.default_context()
+    coefs = filters.make_erb_filters(16000, filters.centre_freqs(16000, 128, 100))
+    lens = [16128, 16129, 16320, 7936, 7937, 65280, 65281, 12000]
+    waves = [orc.synth_utterance(700 + i, n) for i, n in enumerate(lens)]
+    got, _ = fused(ctx, waves, coefs, True, spectral=1)
+    assert int(ctx.get_option("spectral_routed")) == 4           # 16128, 7936, 65280, 12000: at least 256 padding samples
+    for w, g in zip(waves, got):
+        assert chan_relerr(g, orc.filter_and_envelope(w, coefs, True, 50)) <= TOL, len(w)
+    got, _ = fused(ctx, waves, coefs, True, spectral=1, spectral_min_pad=64)
+    assert int(ctx.get_option("spectral_routed")) == len(lens)
+    # a bank whose slowest channel rings longer needs more: 50 Hz -> ERB 30.1 Hz -> peak at 249 samples -> 288
+    coefs50 = filters.make_erb_filters(16000, filters.centre_freqs(16000, 16, 50))
+    lens = [16384 - 288, 16384 - 287]
+    waves = [orc.synth_utterance(720 + i, n) for i, n in enumerate(lens)]
+    got, _ = fused(ctx, waves, coefs50, True, spectral=1)
+    assert int(ctx.get_option("spectral_routed")) == 1
+    for w, g in zip(waves, got):
+        assert chan_relerr(g, orc.filter_and_envelope(w, coefs50, True, 50)) <= TOL, len(w)
 
 
 def test_float64_waves_and_small_tables():

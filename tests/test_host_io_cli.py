@@ -376,3 +376,66 @@ def test_atomic_npy_save_and_resume_check(tmp_path):
     rep4 = iopipe.JobReport("prepare envelope", skip_existing=True)
     assert rep4.pending([str(src)], outs, params={"cutoff": 100}, stamp_dir=str(tmp_path)) == [] and rep4.skipped == 1
     assert sorted(f.name for f in tmp_path.iterdir() if f.name.startswith(".f2cnn")) == [".f2cnn_prepare_envelope.json"]
+
+
+def test_keras_hdf5_model_is_read_through_h5py_when_present(tmp_path, monkeypatch):
+    """`last_trained_model` as the reference writes it (keras model.save, Training.py:139) is an HDF5 file. The loader goes
+    through h5py; the image has none, so a stand-in with h5py's File / Group / Dataset / attrs interface holds a model the way
+    Keras 2.2 lays it out (model_weights/<layer>/<layer>/kernel:0, layer_names / weight_names attributes as bytes, layers
+    without weights in between). Without h5py the loader says how to convert instead of failing obscurely."""
+    import sys
+    import types
+    import numpy as np
+    import pytest
+    from f2cnn_amd import model as mdl
+    ref = mdl.F2CNNModel.glorot(11, zero_bias=False)
+    path = tmp_path / "last_trained_model"
+    path.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+
+    class Node(dict):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.attrs = {}
+
+    def keras_layout():
+        root, mw = Node(), Node()
+        root["model_weights"] = mw
+        root["optimizer_weights"] = Node()
+        layers = [("conv2d_1", "conv1"), ("conv2d_2", "conv2"), ("max_pooling2d_1", None), ("dropout_1", None),
+                  ("conv2d_3", "conv3"), ("conv2d_4", "conv4"), ("max_pooling2d_2", None), ("dropout_2", None),
+                  ("flatten_1", None), ("dense_1", "dense1"), ("dropout_3", None), ("dense_2", "dense2")]
+        mw.attrs["layer_names"] = np.array([n.encode() for n, _ in layers])
+        for lname, ours in layers:
+            g = Node()
+            mw[lname] = g
+            if ours is None:
+                g.attrs["weight_names"] = np.array([], dtype="S1")
+                continue
+            g.attrs["weight_names"] = np.array([f"{lname}/kernel:0".encode(), f"{lname}/bias:0".encode()])
+            inner = Node({"kernel:0": ref.tensors[ours + "_w"], "bias:0": ref.tensors[ours + "_b"]})
+            g[lname] = inner
+
+        def getitem(node, key):      # h5py resolves 'a/b' paths
+            for part in key.split("/"):
+                node = dict.__getitem__(node, part)
+            return node
+        Node.__getitem__ = getitem
+        return root
+
+    class File:
+        def __init__(self, p, mode="r"):
+            assert str(p) == str(path) and mode == "r"
+            self.root = keras_layout()
+
+        def __enter__(self):
+            return self.root
+
+        def __exit__(self, *exc):
+            return False
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    got = mdl.load_model(str(path))
+    for k, v in ref.tensors.items():
+        np.testing.assert_array_equal(got.tensors[k], v)
+    monkeypatch.setitem(sys.modules, "h5py", None)           # import h5py -> ImportError
+    with pytest.raises(ImportError, match="f2cnn_amd.model"):
+        mdl.load_model(str(path))
