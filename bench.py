@@ -43,24 +43,25 @@ F64_PEAK_TFLOPS = 78.6         # f64 vector peak (spec); tools/ubench/fma64_oper
 K1_FLOP_PER_SAMPLE_CHANNEL = 2 * 13   # 13 float64 FMAs per sample-channel
 CNN_FLOP_PER_WINDOW = 2 * 20990472    # SURVEY 8a row a13 (11 x 128 window)
 CNN_SPLIT_FLOP_PER_WINDOW = 2 * 9 * (32 * 32 * 9 * 126 + 32 * 64 * 4 * 63 + 64 * 64 * 2 * 61) + 2 * 1920 * 516   # conv2-conv4 + dense1
-BF16_PEAK_TFLOPS = 2500.0      # dense bf16 matrix peak (MI355X_MICROARCH.md)
+BF16_PEAK_TFLOPS = 2500.0      # dense 16-bit (fp16 = bf16) matrix peak (MI355X_MICROARCH.md)
 
 
 def cnn_accounting(ctx, flop, cnn_s, windows):
-    """The CNN stage against the matrix peak of the arithmetic it runs in. With option cnn_bf16x3 (default) conv2-conv4 and
-    dense1 issue three v_mfma_f32_32x32x16_bf16 per product (operands split in two bf16 pieces, f32 accumulation): `issued`
-    flops = 3 x those layers' flops + the rest at face value, priced against the bf16 peak; TFLOPps stays the algorithmic
+    """The CNN stage against the matrix peak of the arithmetic it runs in. With option cnn_f16x3 (default) conv2-conv4 and
+    dense1 issue three v_mfma_f32_32x32x16_f16 per product (operands split in two fp16 pieces, f32 accumulation): `issued`
+    flops = 3 x those layers' flops + the rest at face value, priced against the fp16 (= bf16) peak; TFLOPps stays the algorithmic
     (float32-equivalent) rate, which is what audio-seconds/s follows."""
-    split = bool(ctx.get_option("cnn_bf16x3"))
+    split = bool(ctx.get_option("cnn_f16x3"))
     out = {"TFLOPps": round(flop / cnn_s / 1e12, 2), "f32_matrix_peak_TFLOPps": F32_PEAK_TFLOPS,
            "vs_f32_matrix_peak": round(flop / cnn_s / 1e12 / F32_PEAK_TFLOPS, 4), "flop_per_window": CNN_FLOP_PER_WINDOW}
     if split:
         issued = flop + 2 * CNN_SPLIT_FLOP_PER_WINDOW * windows
-        out.update({"arithmetic": "conv2-conv4, dense1: v_mfma_f32_32x32x16_bf16 x 3 per product (operands split in two bf16 "
-                                  "pieces, f32 accumulate); conv1, dense2: f32",
+        out.update({"arithmetic": "conv2-conv4, dense1: v_mfma_f32_32x32x16_f16 x 3 per product (operands scaled by powers of two "
+                                  "and split in two fp16 pieces, f32 accumulate: float32 rounding level); conv1 likewise on the "
+                                  "weight-stationary path; dense2: f32",
                     "issued_TFLOPps": round(issued / cnn_s / 1e12, 1), "peak_TFLOPps": BF16_PEAK_TFLOPS,
                     "frac": round(issued / cnn_s / 1e12 / BF16_PEAK_TFLOPS, 4),
-                    "frac_is": "ISSUED flops (three MFMAs per product) / bf16 dense peak",
+                    "frac_is": "ISSUED flops (three MFMAs per product) / fp16 (= bf16) dense peak",
                     "algorithmic_frac_of_bf16_peak": round(flop / cnn_s / 1e12 / BF16_PEAK_TFLOPS, 4),
                     "kernels": "weight-stationary (cnn_ws)" if ctx.get_option("cnn_ws") else "one workgroup per tile"})
     else:
@@ -794,7 +795,7 @@ def main():
                    "value": round(sum(r["audio_s"] for r in res) / elapsed, 2), "unit": "audio-seconds/s",
                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                    "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                   "vs_baseline": None, "dtype": f"f64 IIR + {args.fft} FFT + f32 CNN (conv2-conv4, dense1 products as 3 split-bf16 MFMAs, f32 accumulate)", "data": "synthetic",
+                   "vs_baseline": None, "dtype": f"f64 IIR + {args.fft} FFT + f32 CNN (conv2-conv4, dense1 products as 3 split-fp16 MFMAs, f32 accumulate)", "data": "synthetic",
                    "config": {"workload": blk["workload"], "batch_per_gpu": B, "channels": C, "samples_per_utterance": N,
                               "sample_rate": FS, "lpf_hz": 0, "parallelism": f"utterance-sharded x{world}, no collective"},
                    "roofline": {"bound": "mfma", "kernel": "k_cnn_forward",
@@ -847,12 +848,12 @@ def main():
         if world == 1 and C == 128:
             blocks["cfg4"] = block_cfg4(ctx, coefs, _lib.FFT_F32, 8, N, 2, 1, ranks, with_cpu)[0]
             # the same with every product of the CNN in exact float32 (v_mfma_f32_32x32x2_f32): the figure without the
-            # split-bf16 asterisk (north star: identical labels)
-            ctx.set_option("cnn_bf16x3", 0)
+            # split asterisk (north star: identical labels)
+            ctx.set_option("cnn_f16x3", 0)
             try:
                 b32 = block_cfg4(ctx, coefs, _lib.FFT_F32, 8, N, 1, 1, ranks, False)[0]
             finally:
-                ctx.set_option("cnn_bf16x3", 1)
+                ctx.set_option("cnn_f16x3", 1)
             blocks["cfg4_cnn_f32"] = {k: b32[k] for k in ("workload", "value", "unit", "steps", "ms_per_step", "cnn")}
         if world == 1:
             ctx.synchronize()

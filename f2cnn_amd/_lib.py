@@ -114,7 +114,12 @@ def load(build_if_missing=True):
         _share_hip_runtime_with_torch()
         lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                if os.environ.get("F2CNN_PROBE_OLD_LIB") == "1":   # tools/ab_old_new.sh: an older build beside the tree's
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
         _lib = lib
         return lib

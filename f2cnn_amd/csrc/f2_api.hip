@@ -306,7 +306,8 @@ const opt_entry kOptions[] = {
     {"k1_qwaves", &f2_ctx::opt_k1_qwaves, nullptr, 0, 1 << 20},
     {"env_pair", &f2_ctx::opt_env_pair, nullptr, 0, 1},
     {"env_plan4", &f2_ctx::opt_env_plan4, nullptr, 0, 1},
-    {"cnn_bf16x3", &f2_ctx::opt_cnn_bf16x3, nullptr, 0, 1},
+    {"cnn_f16x3", &f2_ctx::opt_cnn_bf16x3, nullptr, 0, 1},
+    {"cnn_bf16x3", &f2_ctx::opt_cnn_bf16x3, nullptr, 0, 1},   // the option's name in rounds 3-4 (bf16 pieces then): same switch
     {"cnn_ws", &f2_ctx::opt_cnn_ws, nullptr, 0, 1},
     {"cnn_ws_dense", &f2_ctx::opt_cnn_ws_dense, nullptr, 0, 1},
     {"gather_blocked", &f2_ctx::opt_gather_blocked, nullptr, 0, 1},

@@ -7,9 +7,9 @@
 //
 // Accumulation is float32 throughout (what Keras/TensorFlow computes). conv2..conv4 and dense1 (98 % of the 21.0 M MAC
 // per window) run as implicit GEMMs on the matrix cores: the f32-input ones (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf
-// chain, so results are deterministic) or, for conv2..conv4 by default (option cnn_bf16x3), the bf16 ones with both
-// operands split in two bf16 pieces - three MFMAs per product, scores within 1e-6 of the former (k_conv12_bf16x3,
-// k_conv34_bf16x3 below). In the float32 kernels the weights are used in
+// chain, so results are deterministic) or, for conv2..conv4 and dense1 by default (option cnn_f16x3), the fp16 ones with both
+// operands split in two fp16 pieces - three MFMAs per product, scores at the float32 rounding level of the former
+// (f2_cnn_split.h; k_conv12_h16x3, k_conv34_h16x3 below). In the float32 kernels the weights are used in
 // their Keras layouts: a (3,3,Cin,Cout) HWIO kernel flattened is exactly the K x N operand
 // (k = (dy*3+dx)*Cin + ci). Activations are NHWC in HBM between layers, processed in chunks of windows.
 //
@@ -22,13 +22,14 @@
 // pooled row is the wave's second M-tile, so pooling needs no cross-lane traffic (k_conv3x3_mfma). The reference's
 // window shape runs two fused kernels instead: k_conv12_mfma (conv1 computed inside conv2's staging, two waves per
 // task) and k_conv34_mfma (conv3's output stays in LDS).
+#include <algorithm>
+#include <cmath>
+
 #include "f2_internal.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C1 = 32, C2 = 32, C3 = 64, C4 = 64, D1 = 516, D2 = 2;
 constexpr int PW = 34;  // patch width: 32 output columns + 2
@@ -445,27 +446,23 @@ __global__ __launch_bounds__(256) void k_conv34_mfma(const float* __restrict__ i
     }
 }
 
-// ---- the same kernel on the bf16 matrix cores, operands split in two bf16 pieces (option "cnn_bf16x3") ----
-// v_mfma_f32_32x32x16_bf16 runs at 16 x the rate of v_mfma_f32_32x32x2_f32. With a = a1 + a2, a1 = bf16(a), a2 = bf16(a - a1)
-// (round to nearest even, v_cvt_pk_bf16_f32) and the same for the weights, a1 b1 + a1 b2 + a2 b1 - three MFMAs with float32
-// accumulation, 5.3 x the f32 matrix rate - carries the product to ~2^-16 per term; on the cfg4 windows that moves the
-// scores by < 1e-6 and no label outside a float64-referee tie (tests/diag/bf16_split_experiment.py).
+// ---- the same kernel on the fp16 matrix cores, operands split in two fp16 pieces (option "cnn_f16x3"; f2_cnn_split.h) ----
+// Three MFMAs per product with float32 accumulation, 5.3 x the f32 matrix rate. (Rounds 3-4 used bf16 pieces: 2^-16 per product,
+// scores within 7e-7 and two referee ties among the 113 920 cfg4 labels; fp16 pieces with per-layer power-of-two scales carry
+// 2^-22: float32 rounding level, every label identical.)
 // Layouts: lane (i, h) of an MFMA supplies K = 8 h .. 8 h + 7 of row / column i, so 16 input channels are one MFMA step and a
-// lane's operand is ONE 16-byte read of a pixel's channels: patches are [pixel][channel] bf16 (pitch + 16 bytes: conflict-
-// free ds_read_b128), one for the first pieces and one for the second; weights arrive pre-split from the host as
-// w[piece][tap][kb][h][cout][8]. Activations are split where they are written into LDS (staging, conv3's epilogue).
+// lane's operand is ONE 16-byte read of a pixel's channels: patches are [pixel][channel] fp16 (pitch + 16 bytes: conflict-
+// free ds_read_b128), one for the first pieces and one for the second; weights arrive pre-split (and scaled) from the host as
+// w[piece][tap][kb][h][cout][8]. Activations are split where they are written into LDS (staging, conv3's epilogue); between the
+// kernels they travel as float32 in the NEXT layer's scaled units.
 constexpr int PA16 = C2 * 2 + 16;   // bytes per pixel of the conv3 input patches
 constexpr int PB16 = C3 * 2 + 16;   // ... of the conv4 input patches
 
-__device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
-    hi = (__bf16)v;
-    lo = (__bf16)(v - (float)hi);
-}
-
-__global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__ in, const bf16x8* __restrict__ w3s,
-                                                       const float* __restrict__ b3, const bf16x8* __restrict__ w4s,
+__global__ __launch_bounds__(256) void k_conv34_h16x3(const float* __restrict__ in, const h16x8* __restrict__ w3s,
+                                                       const float* __restrict__ b3, const h16x8* __restrict__ w4s,
                                                        const float* __restrict__ b4, float* __restrict__ out, int Win,
-                                                       int xtiles, int64_t nwin) {
+                                                       int xtiles, int64_t nwin, f2_split_scales S) {
+    // (in: pooled conv2 outputs x sa_3; b3 = conv3's biases x sa_4, b4 = conv4's x sa_dense1; out x sa_dense1)
     constexpr int NA = 6 * PW * PA16, NB = 4 * PW * PB16;     // bytes per piece
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     // The second piece of the conv4 input lives where the conv3 input was (a barrier between conv3's matrix loop and its
@@ -492,14 +489,14 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (yi >= 0 && yi < 4 && xi >= 0 && xi < Win)
             v = *reinterpret_cast<const float4*>(img + ((int64_t)yi * Win + xi) * C2 + c4 * 4);
-        __bf16 h4[4], l4[4];
-        split_bf16(v.x, h4[0], l4[0]);
-        split_bf16(v.y, h4[1], l4[1]);
-        split_bf16(v.z, h4[2], l4[2]);
-        split_bf16(v.w, h4[3], l4[3]);
-        const bf16x4 vh = {h4[0], h4[1], h4[2], h4[3]}, vl = {l4[0], l4[1], l4[2], l4[3]};
-        *reinterpret_cast<bf16x4*>(pAh + (r * PW + p) * PA16 + c4 * 8) = vh;
-        *reinterpret_cast<bf16x4*>(pAl + (r * PW + p) * PA16 + c4 * 8) = vl;
+        _Float16 h4[4], l4[4];
+        split_h16(v.x, h4[0], l4[0]);
+        split_h16(v.y, h4[1], l4[1]);
+        split_h16(v.z, h4[2], l4[2]);
+        split_h16(v.w, h4[3], l4[3]);
+        const h16x4 vh = {h4[0], h4[1], h4[2], h4[3]}, vl = {l4[0], l4[1], l4[2], l4[3]};
+        *reinterpret_cast<h16x4*>(pAh + (r * PW + p) * PA16 + c4 * 8) = vh;
+        *reinterpret_cast<h16x4*>(pAl + (r * PW + p) * PA16 + c4 * 8) = vl;
     }
     __syncthreads();
 
@@ -512,17 +509,17 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
         const int pa0 = (wave * PW + i) * PA16 + h * 16;
-        const bf16x8* wh = w3s + h * C3 + i;                  // [tap][kb][h][cout]
-        const bf16x8* wl = wh + 9 * KB * 2 * C3;
+        const h16x8* wh = w3s + h * C3 + i;                  // [tap][kb][h][cout]
+        const h16x8* wl = wh + 9 * KB * 2 * C3;
         // A (LDS) one step ahead; B (weights, L2: a step is only 192 matrix-core cycles) WD steps ahead
         constexpr int WD = 4;
-        bf16x8 ah[2], al[2], bh[WD][2], bl[WD][2];
+        h16x8 ah[2], al[2], bh[WD][2], bl[WD][2];
         auto fetch_a = [&](int it, int buf) {
             const int tap = it / KB, kb = it - tap * KB;
             const int dy = tap / 3, dx = tap - dy * 3;
             const int off = pa0 + (dy * PW + dx) * PA16 + kb * 32;
-            ah[buf] = *reinterpret_cast<const bf16x8*>(pAh + off);
-            al[buf] = *reinterpret_cast<const bf16x8*>(pAl + off);
+            ah[buf] = *reinterpret_cast<const h16x8*>(pAh + off);
+            al[buf] = *reinterpret_cast<const h16x8*>(pAl + off);
         };
         auto fetch_b = [&](int it, int slot) {
             const int wo = it * 2 * C3;                       // (tap * KB + kb) = it
@@ -542,9 +539,9 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[ws][nt], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[ws][nt], acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[ws][nt], acc[nt], 0, 0, 0);
+                acc[nt] = MFMA16(al[cur], bh[ws][nt], acc[nt]);
+                acc[nt] = MFMA16(ah[cur], bl[ws][nt], acc[nt]);
+                acc[nt] = MFMA16(ah[cur], bh[ws][nt], acc[nt]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -561,10 +558,10 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int px = (q & 3) + 8 * (q >> 2) + 4 * h;
-                __bf16 vh, vl;
-                split_bf16(fmaxf(acc[nt][q] + bv, 0.f), vh, vl);
-                *reinterpret_cast<__bf16*>(pBh + (wave * PW + px) * PB16 + co * 2) = vh;
-                *reinterpret_cast<__bf16*>(pBl + (wave * PW + px) * PB16 + co * 2) = vl;
+                _Float16 vh, vl;
+                split_h16(fmaxf(fmaf(acc[nt][q], S.c3, bv), 0.f), vh, vl);
+                *reinterpret_cast<_Float16*>(pBh + (wave * PW + px) * PB16 + co * 2) = vh;
+                *reinterpret_cast<_Float16*>(pBl + (wave * PW + px) * PB16 + co * 2) = vl;
             }
         }
     }
@@ -578,16 +575,16 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
     {
         constexpr int KB = C3 / 16, NIT = 9 * KB;
         const int pa0 = (r4 * PW + i) * PB16 + h * 16;
-        const bf16x8* wh = w4s + h * C4 + nt4 * 32 + i;
-        const bf16x8* wl = wh + 9 * KB * 2 * C4;
+        const h16x8* wh = w4s + h * C4 + nt4 * 32 + i;
+        const h16x8* wl = wh + 9 * KB * 2 * C4;
         constexpr int WD = 6;
-        bf16x8 ah[2], al[2], bh[WD], bl[WD];
+        h16x8 ah[2], al[2], bh[WD], bl[WD];
         auto fetch_a = [&](int it, int buf) {
             const int tap = it / KB, kb = it - tap * KB;
             const int dy = tap / 3, dx = tap - dy * 3;
             const int off = pa0 + (dy * PW + dx) * PB16 + kb * 32;
-            ah[buf] = *reinterpret_cast<const bf16x8*>(pBh + off);
-            al[buf] = *reinterpret_cast<const bf16x8*>(pBl + off);
+            ah[buf] = *reinterpret_cast<const h16x8*>(pBh + off);
+            al[buf] = *reinterpret_cast<const h16x8*>(pBl + off);
         };
         auto fetch_b = [&](int it, int slot) {
             bh[slot] = wh[it * 2 * C4];
@@ -602,9 +599,9 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
             if (it + WD - 1 < NIT) fetch_b(it + WD - 1, (it + WD - 1) % WD);
             if (it + 1 < NIT) fetch_a(it + 1, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[ws], acc4, 0, 0, 0);
-            acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[ws], acc4, 0, 0, 0);
-            acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[ws], acc4, 0, 0, 0);
+            acc4 = MFMA16(al[cur], bh[ws], acc4);
+            acc4 = MFMA16(ah[cur], bl[ws], acc4);
+            acc4 = MFMA16(ah[cur], bh[ws], acc4);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -628,13 +625,13 @@ __global__ __launch_bounds__(256) void k_conv34_bf16x3(const float* __restrict__
             const int xl = (q & 3) + 8 * (q >> 2) + 4 * h;
             const int pxp = (c0 + xl) >> 1;
             const float m = fmaxf(hm[k], xch[k * 64 + lane]);
-            if (xl < T34 && pxp < Wp) o[(int64_t)pxp * C4 + co] = fmaxf(m + bv, 0.f);
+            if (xl < T34 && pxp < Wp) o[(int64_t)pxp * C4 + co] = fmaxf(fmaf(m, S.c4, bv), 0.f);
         }
     }
 }
 
-// ---- conv1 + conv2 + pool with conv2 on the bf16 matrix cores (as k_conv34_bf16x3; structure of k_conv12_mfma) ----
-// The conv2 input patch (computed by conv1, float32 VALU as before) is written as two bf16 pieces at 64 bytes per pixel:
+// ---- conv1 + conv2 + pool with conv2 on the fp16 matrix cores (as k_conv34_h16x3; structure of k_conv12_mfma) ----
+// The conv2 input patch (computed by conv1, float32 VALU as before, then scaled by sa_2) is written as two fp16 pieces at 64 bytes per pixel:
 // no room for a padded pitch (four tasks per workgroup, two workgroups per CU), so the 16-byte chunk c of pixel p sits at
 // chunk c ^ ((p >> 2) & 3) - sixteen consecutive pixels then cover all sixteen bank quads for any chunk a wave reads.
 __device__ __forceinline__ int patch16_offset(int pixel, int chunk) { return pixel * 64 + ((chunk ^ ((pixel >> 2) & 3)) << 4); }
@@ -645,10 +642,11 @@ __device__ __forceinline__ int patch16_offset(int pixel, int chunk) { return pix
 // loads, the conv1 weight loads and the barriers are shared by twice the output (1.14 -> 0.98 ms per 14 240 windows; RP = 4,
 // ten patch rows for eight output rows in an 8-wave workgroup, measured the same as RP = 2).
 template <int RP, int TPW>
-__global__ __launch_bounds__(128 * RP * TPW) void k_conv12_bf16x3(const float* __restrict__ x, const float* __restrict__ w1,
-                                                                   const float* __restrict__ b1, const bf16x8* __restrict__ w2s,
+__global__ __launch_bounds__(128 * RP * TPW) void k_conv12_h16x3(const float* __restrict__ x, const float* __restrict__ w1,
+                                                                   const float* __restrict__ b1, const h16x8* __restrict__ w2s,
                                                                    const float* __restrict__ b2, float* __restrict__ out, int Hin,
-                                                                   int Win, int64_t nwin) {
+                                                                   int Win, int64_t nwin, f2_split_scales S) {
+    // (b2 = conv2's biases x sa_3; out x sa_3)
     constexpr int PR = 2 * RP + 2, PIECE = PR * PW * 64, XW = PW + 2, XR = PR + 2, KB = C1 / 16, NIT = 9 * KB;
     constexpr int TW = 2 * RP;                                 // waves per task
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
@@ -695,17 +693,17 @@ __global__ __launch_bounds__(128 * RP * TPW) void k_conv12_bf16x3(const float* _
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) xv[dy * 3 + dx] = xin[(pr + dy) * XW + pc + dx];
-        __bf16 h4[4], l4[4];
+        _Float16 h4[4], l4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float acc = 0.f;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) acc = fmaf(xv[tap], wr[tap][q], acc);   // same order as the oracle's conv1
-            split_bf16(fmaxf(acc + br[q], 0.f), h4[q], l4[q]);
+            split_h16(fmaxf(acc + br[q], 0.f) * S.sa2, h4[q], l4[q]);
         }
         const int off = patch16_offset(e, c4 >> 1) + (c4 & 1) * 8;
-        *reinterpret_cast<bf16x4*>(ph + off) = bf16x4{h4[0], h4[1], h4[2], h4[3]};
-        *reinterpret_cast<bf16x4*>(pl + off) = bf16x4{l4[0], l4[1], l4[2], l4[3]};
+        *reinterpret_cast<h16x4*>(ph + off) = h16x4{h4[0], h4[1], h4[2], h4[3]};
+        *reinterpret_cast<h16x4*>(pl + off) = h16x4{l4[0], l4[1], l4[2], l4[3]};
     }
     __syncthreads();
 
@@ -714,17 +712,17 @@ __global__ __launch_bounds__(128 * RP * TPW) void k_conv12_bf16x3(const float* _
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     const int p0 = r * PW + i;
-    const bf16x8* wh = w2s + h * C2 + i;                      // [tap][kb][h][cout]
-    const bf16x8* wl = wh + 9 * KB * 2 * C2;
+    const h16x8* wh = w2s + h * C2 + i;                      // [tap][kb][h][cout]
+    const h16x8* wl = wh + 9 * KB * 2 * C2;
     // A (LDS) one step ahead; B (weights, L2) WD steps ahead: a step is only 96 matrix-core cycles
     constexpr int WD = 5;
-    bf16x8 ah[2], al[2], bh[WD], bl[WD];
+    h16x8 ah[2], al[2], bh[WD], bl[WD];
     auto fetch_a = [&](int it, int buf) {
         const int tap = it / KB, kb = it - tap * KB;
         const int dy = tap / 3, dx = tap - dy * 3;
         const int off = patch16_offset(p0 + dy * PW + dx, 2 * kb + h);
-        ah[buf] = *reinterpret_cast<const bf16x8*>(ph + off);
-        al[buf] = *reinterpret_cast<const bf16x8*>(pl + off);
+        ah[buf] = *reinterpret_cast<const h16x8*>(ph + off);
+        al[buf] = *reinterpret_cast<const h16x8*>(pl + off);
     };
     auto fetch_b = [&](int it, int slot) {
         bh[slot] = wh[it * 2 * C2];
@@ -739,9 +737,9 @@ __global__ __launch_bounds__(128 * RP * TPW) void k_conv12_bf16x3(const float* _
         if (it + WD - 1 < NIT) fetch_b(it + WD - 1, (it + WD - 1) % WD);
         if (it + 1 < NIT) fetch_a(it + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[ws], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[ws], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[ws], acc, 0, 0, 0);
+        acc = MFMA16(al[cur], bh[ws], acc);
+        acc = MFMA16(ah[cur], bl[ws], acc);
+        acc = MFMA16(ah[cur], bh[ws], acc);
         __builtin_amdgcn_sched_barrier(0);
     }
     // 2x2 pool: horizontal pairs sit in one lane; the odd row of a pair hands its eight pair maxima to the even one through
@@ -765,24 +763,27 @@ __global__ __launch_bounds__(128 * RP * TPW) void k_conv12_bf16x3(const float* _
             const int q = 2 * k;
             const int px = (x0 + (q & 3) + 8 * (q >> 2) + 4 * h) >> 1;
             const float m = fmaxf(hm[k], xch[k * 64 + lane]);
-            if (px < Wout) o[((int64_t)rp * Wout + px) * C2 + i] = fmaxf(m + bv, 0.f);
+            if (px < Wout) o[((int64_t)rp * Wout + px) * C2 + i] = fmaxf(fmaf(m, S.c2, bv), 0.f);
         }
     }
 }
 
+// `fused`: the outputs feed k_conv34_h16x3 (scaled by sa_3); otherwise the float32 conv3 (true units)
 template <int RP, int TPW>
-int launch_conv12_bf16(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, float* a2, int H1, int W1, int64_t n) {
+int launch_conv12_h16(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, float* a2, int H1, int W1, int64_t n, bool fused) {
     const int Ho = H1 - 2, Wo = W1 - 2;
     const int64_t tasks = n * (Ho / 2 / RP) * (((Wo / 2) * 2 + 31) / 32);
     if (tasks <= 0) return F2_OK;
     constexpr size_t lds = TPW * (2 * (size_t)((2 * RP + 2) * PW * 64) + sizeof(float) * (2 * RP + 4) * (PW + 2));
     static_assert(lds <= 80 * 1024, "at least two workgroups per CU");
-    auto kern = k_conv12_bf16x3<RP, TPW>;
+    auto kern = k_conv12_h16x3<RP, TPW>;
     F2_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t blocks = (tasks + TPW - 1) / TPW;
     F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
+    f2_split_scales sc = cnn->sc;
+    if (!fused) sc.c2 = cnn->c2_true;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(128 * RP * TPW), lds, ctx->stream, d_x, cnn->t(0), cnn->t(1),
-                       (const bf16x8*)(cnn->blob16 + cnn->off16[0]), cnn->t(3), a2, H1, W1, n);
+                       (const h16x8*)(cnn->blob16 + cnn->off16[0]), fused ? cnn->sbias + F2_SB_B2 : cnn->t(3), a2, H1, W1, n, sc);
     return F2_OK;
 }
 
@@ -865,19 +866,19 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_mfma(const float* __re
     }
 }
 
-// ---- dense1 on the bf16 matrix cores, operands split in two pieces (as the convolutions above) ----
+// ---- dense1 on the fp16 matrix cores, operands split in two pieces (as the convolutions above; a = conv4 outputs x sa_dense1) ----
 // Same tiling as k_dense1_mfma (64 windows x 6 output tiles per 6-wave workgroup, K in chunks of 64). A chunk is only 24
 // MFMAs per wave now, so the next chunk's activations (global -> registers) and weights (8 x 16 bytes per lane) are
 // requested before the current chunk's MFMAs and land while they run; the activations are split when they are written to
-// LDS ([row][64] bf16 per piece, pitch + 16 bytes). Weights: w[piece][chunk][ks][h][n (544)][8], k = 64 chunk + 16 ks + 8 h + e.
+// LDS ([row][64] fp16 per piece, pitch + 16 bytes). Weights: w[piece][chunk][ks][h][n (544)][8], k = 64 chunk + 16 ks + 8 h + e.
 constexpr int D1_PITCH16 = D1_KC * 2 + 16;
 // MT = M tiles (32 windows each) per workgroup. With 64 windows (MT = 2) a 14 240-window chunk is 223 x 3 = 669 workgroups for
 // the 512 that are resident at two per CU: a second round one third full. 96 windows (MT = 3): 149 x 3 = 447 workgroups, one
 // round, and every weight fragment feeds nine MFMAs instead of six.
 template <int MT>
-__global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_bf16x3(const float* __restrict__ a, const bf16x8* __restrict__ ws,
+__global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_h16x3(const float* __restrict__ a, const h16x8* __restrict__ ws,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
-                                                                 int K, int64_t n) {
+                                                                 int K, int64_t n, f2_split_scales S) {
     constexpr int D1_MT = MT;
     constexpr int ROWS = 32 * D1_MT, NTHR = D1_WAVES * 64;
     constexpr int PER = (ROWS * (D1_KC / 4) + NTHR - 1) / NTHR;      // float4 of a chunk per thread (3, the last partly)
@@ -890,8 +891,8 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_bf16x3(const float* __
     const int nt = blockIdx.y * D1_WAVES + wave;
     const bool live = nt < D1_TILES;
     const int ntc = live ? nt : D1_TILES - 1;                        // (idle waves load a valid tile and discard it)
-    const bf16x8* wh = ws + (int64_t)h * D1_NPAD + ntc * 32 + i;
-    const bf16x8* wl = wh + (int64_t)nchunks * 4 * 2 * D1_NPAD;
+    const h16x8* wh = ws + (int64_t)h * D1_NPAD + ntc * 32 + i;
+    const h16x8* wl = wh + (int64_t)nchunks * 4 * 2 * D1_NPAD;
 
     float4 ar[PER];
     auto load_a = [&](int kc) {
@@ -909,17 +910,17 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_bf16x3(const float* __
             const int e = tid + p * NTHR;
             const int row = e / (D1_KC / 4), c4 = e - row * (D1_KC / 4);
             if (e < ROWS * (D1_KC / 4)) {
-                __bf16 h4[4], l4[4];
-                split_bf16(ar[p].x, h4[0], l4[0]);
-                split_bf16(ar[p].y, h4[1], l4[1]);
-                split_bf16(ar[p].z, h4[2], l4[2]);
-                split_bf16(ar[p].w, h4[3], l4[3]);
-                *reinterpret_cast<bf16x4*>(&Ah[buf][row * D1_PITCH16 + c4 * 8]) = bf16x4{h4[0], h4[1], h4[2], h4[3]};
-                *reinterpret_cast<bf16x4*>(&Al[buf][row * D1_PITCH16 + c4 * 8]) = bf16x4{l4[0], l4[1], l4[2], l4[3]};
+                _Float16 h4[4], l4[4];
+                split_h16(ar[p].x * S.sin_d, h4[0], l4[0]);
+                split_h16(ar[p].y * S.sin_d, h4[1], l4[1]);
+                split_h16(ar[p].z * S.sin_d, h4[2], l4[2]);
+                split_h16(ar[p].w * S.sin_d, h4[3], l4[3]);
+                *reinterpret_cast<h16x4*>(&Ah[buf][row * D1_PITCH16 + c4 * 8]) = h16x4{h4[0], h4[1], h4[2], h4[3]};
+                *reinterpret_cast<h16x4*>(&Al[buf][row * D1_PITCH16 + c4 * 8]) = h16x4{l4[0], l4[1], l4[2], l4[3]};
             }
         }
     };
-    bf16x8 bh[2][4], bl[2][4];
+    h16x8 bh[2][4], bl[2][4];
     auto load_b = [&](int kc, int slot) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -950,11 +951,11 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_bf16x3(const float* __
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int t = 0; t < D1_MT; ++t) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pah + t * 32 * D1_PITCH16 + ks * 32);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(pal + t * 32 * D1_PITCH16 + ks * 32);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cur][ks], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cur][ks], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cur][ks], acc[t], 0, 0, 0);
+                const h16x8 ah = *reinterpret_cast<const h16x8*>(pah + t * 32 * D1_PITCH16 + ks * 32);
+                const h16x8 al = *reinterpret_cast<const h16x8*>(pal + t * 32 * D1_PITCH16 + ks * 32);
+                acc[t] = MFMA16(al, bh[cur][ks], acc[t]);
+                acc[t] = MFMA16(ah, bl[cur][ks], acc[t]);
+                acc[t] = MFMA16(ah, bh[cur][ks], acc[t]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(D1_WAVES * 64) void k_dense1_bf16x3(const float* __
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int64_t wr = w0 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (wr < n) out[wr * D1 + col] = fmaxf(acc[t][q] + b, 0.f);
+                if (wr < n) out[wr * D1 + col] = fmaxf(fmaf(acc[t][q], S.cd, b), 0.f);
             }
     }
 }
@@ -1084,8 +1085,8 @@ int f2_launch_cnn_convs(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_
             F2_CHECK(ctx, blocks < (int64_t(1) << 31), F2_ERR_UNSUPPORTED, "CNN chunk too large");
             if (ctx->opt_cnn_bf16x3 && cnn->blob16) {
                 // four output rows per task where the pooled height allows (the reference's 11-row windows: 4 pooled rows)
-                if ((Ho / 2) % 2 == 0) F2_TRY((launch_conv12_bf16<2, 1>(ctx, cnn, d_x, a2, d.H1, d.W1, n)));
-                else F2_TRY((launch_conv12_bf16<1, 2>(ctx, cnn, d_x, a2, d.H1, d.W1, n)));
+                if ((Ho / 2) % 2 == 0) F2_TRY((launch_conv12_h16<2, 1>(ctx, cnn, d_x, a2, d.H1, d.W1, n, d.Hp1 == 4)));
+                else F2_TRY((launch_conv12_h16<1, 2>(ctx, cnn, d_x, a2, d.H1, d.W1, n, d.Hp1 == 4)));
             } else {
                 hipLaunchKernelGGL(k_conv12_mfma, dim3((unsigned)blocks), dim3(512), lds12, ctx->stream, d_x, cnn->t(0), cnn->t(1),
                                    cnn->t(2), cnn->t(3), a2, d.H1, d.W1, n);
@@ -1105,10 +1106,10 @@ int f2_launch_cnn_convs(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_
         if (ctx->opt_cnn_bf16x3 && cnn->blob16) {
             constexpr size_t lds16 = 2 * (size_t)(6 * PW * PA16) + (size_t)(4 * PW * PB16);
             static_assert(3 * lds16 <= 160 * 1024, "three workgroups per CU");
-            F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv34_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-            hipLaunchKernelGGL(k_conv34_bf16x3, dim3((unsigned)blocks), dim3(256), lds16, ctx->stream, a2,
-                               (const bf16x8*)(cnn->blob16 + cnn->off16[1]), cnn->t(5),
-                               (const bf16x8*)(cnn->blob16 + cnn->off16[2]), cnn->t(7), a4, d.Wp1, xtiles, n);
+            F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv34_h16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+            hipLaunchKernelGGL(k_conv34_h16x3, dim3((unsigned)blocks), dim3(256), lds16, ctx->stream, a2,
+                               (const h16x8*)(cnn->blob16 + cnn->off16[1]), cnn->sbias + F2_SB_B3F,
+                               (const h16x8*)(cnn->blob16 + cnn->off16[2]), cnn->sbias + F2_SB_B4, a4, d.Wp1, xtiles, n, cnn->sc);
         } else {
             hipLaunchKernelGGL(k_conv34_mfma, dim3((unsigned)blocks), dim3(256), lds34, ctx->stream, a2, cnn->t(4), cnn->t(5),
                                cnn->t(6), cnn->t(7), a4, d.Wp1, xtiles, n);
@@ -1139,9 +1140,12 @@ int f2_launch_cnn_dense(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t
 #endif
         constexpr int MT16 = F2_D1_MT;   // (3 - 96 windows, one round of workgroups per 14 240-window chunk - measured slower: 0.165 against 0.157 ms)
         const dim3 grid16((unsigned)((n + 32 * MT16 - 1) / (32 * MT16)), (D1_TILES + D1_WAVES - 1) / D1_WAVES);
-        if (ctx->opt_cnn_bf16x3 && cnn->blob16)
-            hipLaunchKernelGGL(k_dense1_bf16x3<MT16>, grid16, dim3(D1_WAVES * 64), 0, ctx->stream, a4,
-                               (const bf16x8*)(cnn->blob16 + cnn->off16[3]), cnn->t(9), a5, d.flat, n);
+        if (ctx->opt_cnn_bf16x3 && cnn->blob16) {
+            f2_split_scales sc = cnn->sc;
+            if (d.Hp1 != 4) sc.sin_d = cnn->sa_d1;     // (conv3 / conv4 of such windows ran on the float32 kernels: true units)
+            hipLaunchKernelGGL(k_dense1_h16x3<MT16>, grid16, dim3(D1_WAVES * 64), 0, ctx->stream, a4,
+                               (const h16x8*)(cnn->blob16 + cnn->off16[3]), cnn->t(9), a5, d.flat, n, sc);
+        }
         else
             hipLaunchKernelGGL(k_dense1_mfma, grid, dim3(D1_WAVES * 64), 0, ctx->stream, a4, cnn->t(8), cnn->t(9), a5, d.flat, n);
         F2_HIP(ctx, hipGetLastError());
@@ -1284,24 +1288,68 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
                     tensors[8][(size_t)k * D1 + nn];
         }
     }
-    // conv2 .. conv4 kernels once more for the split-bf16 kernels: w[piece][tap][kb][h][cout][8] (channel = 16 kb + 8 h + e),
-    // piece 0 = bf16(w), piece 1 = bf16(w - piece 0), round to nearest even
+    // conv2 .. conv4 and dense1 kernels once more for the split-fp16 kernels (f2_cnn_split.h): per-layer power-of-two scales,
+    // w[piece][tap][kb][h][cout][8] (channel = 16 kb + 8 h + e), piece 0 = fp16(w sb), piece 1 = fp16(w sb - piece 0)
     std::vector<uint16_t> w16;
+    std::vector<float> sbias(F2_SB_FLOATS, 0.f);
     {
-        auto to_bf16 = [](float x) -> uint16_t {
-            uint32_t u;
-            memcpy(&u, &x, 4);
-            return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        auto pow2_floor = [](double v) { return v > 0 && std::isfinite(v) ? std::exp2(std::floor(std::log2(v))) : 1.0; };
+        auto clamp_scale = [](double v) { return std::min(std::max(v, std::exp2(-20.0)), std::exp2(20.0)); };
+        // upper bound of a layer's outputs from the L1 norms of its kernel's columns (inputs bounded by `inb`)
+        auto l1_bound = [](const float* w, const float* b, size_t kin, size_t cout, double inb) {
+            double worst = 0.0;
+            for (size_t co = 0; co < cout; ++co) {
+                double acc = 0.0;
+                for (size_t k = 0; k < kin; ++k) acc += std::fabs((double)w[k * cout + co]);
+                worst = std::max(worst, acc * inb + std::fabs((double)b[co]));
+            }
+            return worst;
         };
-        auto from_bf16 = [](uint16_t b) -> float {
-            const uint32_t u = (uint32_t)b << 16;
-            float r;
-            memcpy(&r, &u, 4);
-            return r;
+        auto max_abs = [](const float* w, size_t n) {
+            double m = 0.0;
+            for (size_t k = 0; k < n; ++k) m = std::max(m, std::fabs((double)w[k]));
+            return m;
+        };
+        const size_t kin[4] = {9 * (size_t)C1, 9 * (size_t)C2, 9 * (size_t)C3, (size_t)d.flat};
+        const size_t cout[4] = {C2, C3, C4, D1};
+        const int wi[4] = {2, 4, 6, 8};
+        double sa[5], sb[4];          // sa[l]: input scale of conv2, conv3, conv4, dense1; sa[4] = 1 (dense2 runs in float32)
+        double bound = l1_bound(tensors[0], tensors[1], 9, C1, 1.0);       // conv1 outputs for inputs in [0, 1]
+        for (int l = 0; l < 4; ++l) {
+            sa[l] = clamp_scale(pow2_floor(16384.0 / std::max(bound, 1e-30)));
+            sb[l] = clamp_scale(pow2_floor(2048.0 / std::max(max_abs(tensors[wi[l]], kin[l] * cout[l]), 1e-30)));
+            bound = l1_bound(tensors[wi[l]], tensors[wi[l] + 1], kin[l], cout[l], bound);
+        }
+        sa[4] = 1.0;
+        cnn->sc.sa2 = (float)sa[0];
+        cnn->sc.c2 = (float)(sa[1] / (sa[0] * sb[0]));
+        cnn->sc.c3 = (float)(sa[2] / (sa[1] * sb[1]));
+        cnn->sc.c4 = (float)(sa[3] / (sa[2] * sb[2]));
+        cnn->sc.cd = (float)(1.0 / (sa[3] * sb[3]));
+        cnn->sc.sin_d = 1.f;
+        cnn->c2_true = (float)(1.0 / (sa[0] * sb[0]));
+        cnn->sa_d1 = (float)sa[3];
+        for (int co = 0; co < C2; ++co) sbias[F2_SB_B2 + co] = (float)(tensors[3][co] * sa[1]);
+        for (int co = 0; co < C3; ++co) {
+            sbias[F2_SB_B3I + co] = (float)(tensors[5][co] * (sa[1] * sb[1]));   // accumulator-initial form (f2_cnn_ws.hip)
+            sbias[F2_SB_B3F + co] = (float)(tensors[5][co] * sa[2]);             // epilogue form
+        }
+        for (int co = 0; co < C4; ++co) sbias[F2_SB_B4 + co] = (float)(tensors[7][co] * sa[3]);
+        auto to_f16 = [](float x) -> uint16_t {
+            const _Float16 hv = (_Float16)x;          // round to nearest even, subnormals kept (as v_cvt_f16_f32)
+            uint16_t u;
+            memcpy(&u, &hv, 2);
+            return u;
+        };
+        auto from_f16 = [](uint16_t b) -> float {
+            _Float16 hv;
+            memcpy(&hv, &b, 2);
+            return (float)hv;
         };
         size_t pos = 0;
         for (int l = 0; l < 3; ++l) {
             const int ti = 2 + 2 * l, ci_n = conv_cin[l], co_n = conv_cout[l], kbn = ci_n / 16;
+            const float scale = (float)sb[l];
             cnn->off16[l] = pos;
             const size_t per_piece = (size_t)9 * ci_n * co_n;
             w16.resize(pos + 2 * per_piece);
@@ -1310,8 +1358,8 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
                     for (int hh = 0; hh < 2; ++hh)
                         for (int co = 0; co < co_n; ++co)
                             for (int e2 = 0; e2 < 8; ++e2) {
-                                const float wv = tensors[ti][((size_t)tap * ci_n + 16 * kb + 8 * hh + e2) * co_n + co];
-                                const uint16_t p0 = to_bf16(wv), p1 = to_bf16(wv - from_bf16(p0));
+                                const float wv = tensors[ti][((size_t)tap * ci_n + 16 * kb + 8 * hh + e2) * co_n + co] * scale;
+                                const uint16_t p0 = to_f16(wv), p1 = to_f16(wv - from_f16(p0));
                                 const size_t idx = ((((size_t)tap * kbn + kb) * 2 + hh) * co_n + co) * 8 + e2;
                                 w16[pos + idx] = p0;
                                 w16[pos + per_piece + idx] = p1;
@@ -1319,14 +1367,15 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
             pos += 2 * per_piece;
         }
         {   // dense1: w[piece][chunk][ks][h][n (544, zero beyond 516)][8], k = 64 chunk + 16 ks + 8 h + e
+            const float scale = (float)sb[3];
             cnn->off16[3] = pos;
             const size_t per_piece = (size_t)d.flat * D1_NPAD;
             w16.resize(pos + 2 * per_piece, 0);
             for (int k = 0; k < d.flat; ++k) {
                 const int kc = k / D1_KC, kk = k % D1_KC, ks = kk / 16, hh = (kk % 16) / 8, e2 = kk % 8;
                 for (int nn = 0; nn < D1; ++nn) {
-                    const float wv = tensors[8][(size_t)k * D1 + nn];
-                    const uint16_t p0 = to_bf16(wv), p1 = to_bf16(wv - from_bf16(p0));
+                    const float wv = tensors[8][(size_t)k * D1 + nn] * scale;
+                    const uint16_t p0 = to_f16(wv), p1 = to_f16(wv - from_f16(p0));
                     const size_t idx = ((((size_t)kc * 4 + ks) * 2 + hh) * D1_NPAD + nn) * 8 + e2;
                     w16[pos + idx] = p0;
                     w16[pos + per_piece + idx] = p1;
@@ -1341,6 +1390,8 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
     if (e == hipSuccess) cnn->zeros = cnn->blob16 + zeros_at;
     if (e == hipSuccess)
         e = hipMemcpyAsync(cnn->blob16, w16.data(), w16.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&cnn->sbias, sbias.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(cnn->sbias, sbias.data(), sbias.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     for (int i = 0; e == hipSuccess && i < 12; ++i) {
         const float* src = relaid[i].empty() ? tensors[i] : relaid[i].data();
         e = hipMemcpyAsync(cnn->blob + cnn->off[i], src, dev_sizes[i] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
@@ -1350,6 +1401,7 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
     if (e != hipSuccess) {
         (void)hipFree(cnn->blob);
         if (cnn->blob16) (void)hipFree(cnn->blob16);
+        if (cnn->sbias) (void)hipFree(cnn->sbias);
         delete cnn;
         return f2_fail(ctx, F2_ERR_HIP, "uploading CNN weights -> %s", hipGetErrorString(e));
     }
@@ -1357,6 +1409,7 @@ int f2_cnn_create(f2_ctx* ctx, const float* const* tensors, int rows, int channe
     if (rc != F2_OK) {
         (void)hipFree(cnn->blob);
         (void)hipFree(cnn->blob16);
+        (void)hipFree(cnn->sbias);
         delete cnn;
         return rc;
     }
@@ -1381,6 +1434,7 @@ int f2_cnn_destroy(f2_ctx* ctx, f2_cnn* cnn) {
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (cnn->blob) (void)hipFree(cnn->blob);
     if (cnn->blob16) (void)hipFree(cnn->blob16);
+    if (cnn->sbias) (void)hipFree(cnn->sbias);
     delete cnn;
     return F2_OK;
 }

@@ -1,13 +1,14 @@
-// K4, weight-stationary form of the split-bf16 convolutions (round 4) for the reference's window shape (10 or 11 rows:
+// K4, weight-stationary form of the split-fp16 convolutions (round 4; fp16 pieces and per-layer scales since round 5:
+// f2_cnn_split.h - where this file says "split" it means two fp16 pieces) for the reference's window shape (10 or 11 rows:
 // four pooled rows after conv2). Reference: architecture scripts/CNN/Training.py:93-114, predict scripts/CNN/Evaluating.py:84-87.
 //
-// Why. k_conv12_bf16x3 / k_conv34_bf16x3 (f2_cnn.hip) issue MFMAs 37 % of the time: every 32 x 32 x 16 product loads both of
+// Why. k_conv12_h16x3 / k_conv34_h16x3 (f2_cnn.hip) issue MFMAs 37 % of the time: every 32 x 32 x 16 product loads both of
 // its operands again - the activations from LDS and the weights through the vector L1, 2 KB per wave and step, 85 B/clk/CU
 // against the 64 B/clk the L1 delivers - and conv1 runs as 36 float32 FMAs per pixel and channel quad in front of the matrix loop,
 // in phases that all waves of a workgroup go through together.
 //
 // Here every wave keeps the weights of its role in registers for the whole launch (9 taps x 32 input channels x 32 outputs x 2
-// bf16 pieces = 144 VGPRs; 256 registers per wave, one 8-wave workgroup per CU, persistent over tiles), with ONE barrier per
+// fp16 pieces = 144 VGPRs; 256 registers per wave, one 8-wave workgroup per CU, persistent over tiles), with ONE barrier per
 // tile. What the other instructions cost was measured, not assumed (tools/ws_stamps.py: in-kernel stamps; tools/ubench/
 // mfma_valu_coissue.hip, mfma_fillers.hip; SQ counters under profiles/): beside a partner wave's matrix loop a wave issues only
 // ~2 VALU instructions per MFMA whatever the wave priorities, while up to ~8 per MFMA ride in the gaps of a wave's OWN matrix
@@ -18,11 +19,11 @@
 //                 columns 16 (w >> 2) .. + 15 of tile t (the 32 x 32 accumulator's row index = (row, column): the 2 x 2 max-pool
 //                 stays inside the lane). Riding behind the steps of that matrix loop: conv1 of tile t + 1 for one or two
 //                 blocks of 32 patch pixels ON THE MATRIX CORES - out^T (32 channels x 32 pixels) = W1^T (32 x 16: nine taps,
-//                 the bias against a constant 1, zeros) x taps^T (16 x 32 pixels), three split-bf16 MFMAs; with the channels on
+//                 the bias against a constant 1, zeros) x taps^T (16 x 32 pixels), three split-fp16 MFMAs; with the channels on
 //                 the accumulator's row index a lane holds four consecutive channels of its pixel, so ReLU + split + two 8-byte
 //                 LDS stores per quad write the conv2 input patch - no longer the oracle's fmaf chain bit for bit, held to the
 //                 same 2e-5 / referee rule; the LDS-DMA of the raw input of tile t + 2 (zeros outside the window from a zero
-//                 buffer); bias + ReLU + split + stores of the pooled outputs of tile t - 1. Output already split in two bf16
+//                 buffer); bias + ReLU + split + stores of the pooled outputs of tile t - 1. Output already split in two fp16
 //                 pieces ([window][4][16 x tiles][hi 32 | lo 32]): conv3's staging is a copy.
 //   k_conv34_ws   tile = (window, 30 conv4 columns). waves 0-3: LDS-DMA of tile t + 2 from HBM into the free patch A, conv3 (output
 //                 tile nt, row pair: a patch row fetched from LDS serves tap row dy of one output row and dy - 1 of the other,
@@ -33,7 +34,7 @@
 //   k_dense1_ws   96 windows x 6 output tiles per 6-wave workgroup (two per CU), weights streamed two 16-byte loads per lane
 //                 and K step into a ring, activations split on their way into LDS; every load of the K loop waited for by hand.
 //
-// Layout of an MFMA operand (tools/ubench/mfma_bf16_layout.hip): lane (i, h) supplies k = 8 h .. 8 h + 7 of row / column i;
+// Layout of an MFMA operand (tools/ubench/mfma_bf16_layout.hip, mfma_f16_split.hip: the two forms share it): lane (i, h) supplies k = 8 h .. 8 h + 7 of row / column i;
 // accumulator register q of lane (i, h) is row (q & 3) + 8 (q >> 2) + 4 h, column i.
 #include <type_traits>
 
@@ -42,8 +43,6 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -66,20 +65,13 @@ __device__ __forceinline__ int a32_off(int p, int h) { return p * 32 + ((h ^ ((p
 __device__ __forceinline__ int c32_off(int row, int col, int h) { return (row * PW + col) * 32 + ((h ^ (row & 1)) << 4); }
 __device__ __forceinline__ int b64_off(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
 
-__device__ __forceinline__ void split4(const float v0, const float v1, const float v2, const float v3, bf16x4& hi, bf16x4& lo) {
-    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1, h2 = (__bf16)v2, h3 = (__bf16)v3;
-    hi = bf16x4{h0, h1, h2, h3};
-    lo = bf16x4{(__bf16)(v0 - (float)h0), (__bf16)(v1 - (float)h1), (__bf16)(v2 - (float)h2), (__bf16)(v3 - (float)h3)};
-}
-
 // ReLU as ONE instruction: integer max with 0 on the bit pattern (negative floats are negative integers; fmaxf and v_med3 alike come
 // out of this compiler as a canonicalising v_max(v, v) followed by v_max(0, v))
 __device__ __forceinline__ float relu(float v) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), 0)); }
 
 // a value the compiler must keep in a register from here on (it cannot re-load or re-derive it inside the tile loop)
-__device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(h16x8& v) { asm volatile("" : "+v"(v)); }
 
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 // Issue priority of this wave on its SIMD: high in the VALU / LDS phases, low in the matrix loop (which needs one issue slot per
 // 32 cycles). Measured effect: none either way (tools/ws_stamps.py); kept because it is the documented intent.
 #define PRIO_VALU() __builtin_amdgcn_s_setprio(3)
@@ -118,15 +110,15 @@ __device__ __forceinline__ void tile_split(unsigned t, tile_div td, unsigned& q,
 // output channels, columns = pixels), otherwise the B operand (rows = pixels, columns = output channels).
 // fill(f) rides behind the MFMAs of fragment f (see conv_one_tile); output row 0 is complete once fragment 17 is done.
 template <bool SWAP, int DEPTH, int PLANE, class OFF, class FILL>
-__device__ __forceinline__ void conv_two_rows(f32x16 (&acc)[2], const bf16x8 (&wh)[18], const bf16x8 (&wl)[18],
+__device__ __forceinline__ void conv_two_rows(f32x16 (&acc)[2], const h16x8 (&wh)[18], const h16x8 (&wl)[18],
                                               const unsigned char* ph, const unsigned char* pl, OFF off, FILL fill) {
     constexpr int NF = 24;
-    bf16x8 fh[DEPTH], fl[DEPTH];
+    h16x8 fh[DEPTH], fl[DEPTH];
     auto fetch = [&](int f, int slot) {
         const int pr = f / 6, dx = (f >> 1) % 3, kb = f & 1;
         const int o = off(pr, dx) + kb * PLANE;
-        fh[slot] = *reinterpret_cast<const bf16x8*>(ph + o);
-        fl[slot] = *reinterpret_cast<const bf16x8*>(pl + o);
+        fh[slot] = *reinterpret_cast<const h16x8*>(ph + o);
+        fl[slot] = *reinterpret_cast<const h16x8*>(pl + o);
     };
 #pragma unroll
     for (int f = 0; f < DEPTH - 1; ++f) fetch(f, f);
@@ -170,15 +162,15 @@ __device__ __forceinline__ void conv_two_rows(f32x16 (&acc)[2], const bf16x8 (&w
 // VALU instructions per MFMA for +16 % loop time, tools/ubench/mfma_fillers.hip; a partner wave's VALU beside the loop gets ~2 per
 // MFMA, tools/ubench/mfma_valu_coissue.hip).
 template <int DEPTH, int PLANE, class OFF, class FILL>
-__device__ __forceinline__ void conv_one_tile(f32x16& acc, const bf16x8 (&wh)[18], const bf16x8 (&wl)[18],
+__device__ __forceinline__ void conv_one_tile(f32x16& acc, const h16x8 (&wh)[18], const h16x8 (&wl)[18],
                                               const unsigned char* ph, const unsigned char* pl, OFF off, FILL fill) {
     constexpr int NF = 18;
-    bf16x8 fh[DEPTH], fl[DEPTH];
+    h16x8 fh[DEPTH], fl[DEPTH];
     auto fetch = [&](int f, int slot) {
         const int tap = f >> 1, kb = f & 1, dy = tap / 3, dx = tap - 3 * dy;
         const int o = off(dy, dx) + kb * PLANE;
-        fh[slot] = *reinterpret_cast<const bf16x8*>(ph + o);
-        fl[slot] = *reinterpret_cast<const bf16x8*>(pl + o);
+        fh[slot] = *reinterpret_cast<const h16x8*>(ph + o);
+        fl[slot] = *reinterpret_cast<const h16x8*>(pl + o);
     };
 #pragma unroll
     for (int f = 0; f < DEPTH - 1; ++f) fetch(f, f);
@@ -237,10 +229,10 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // of its one or two pixel blocks of t_(k+1) (from the raw input that landed an iteration ago, into patch buffer (k + 1) & 1), the
 // stores of its pooled outputs of t_(k-1). The first two and the last two iterations run the same pieces one after the other.
 __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, const float* __restrict__ w1,
-                                                   const float* __restrict__ b1, const bf16x8* __restrict__ w2s,
-                                                   const float* __restrict__ b2, __bf16* __restrict__ out,
+                                                   const float* __restrict__ b1, const h16x8* __restrict__ w2s,
+                                                   const float* __restrict__ b2 /* x sa_3 */, _Float16* __restrict__ out,
                                                    const float* __restrict__ zeros, int Hin, int Win, int Wa, tile_div xt,
-                                                   unsigned ntask WS_STAMP_ARG) {
+                                                   unsigned ntask, f2_split_scales S WS_STAMP_ARG) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const ldsP = lds + 2 * XIN_STRIDE;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: roles, LDS-DMA targets)
@@ -255,10 +247,10 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
     }
 
     // conv2 weights of every wave: B operand, [piece][tap][kb][h][cout]
-    bf16x8 wh[18], wl[18];
+    h16x8 wh[18], wl[18];
     {
-        const bf16x8* ph = w2s + h * C2 + i;
-        const bf16x8* pl = ph + 18 * 2 * C2;
+        const h16x8* ph = w2s + h * C2 + i;
+        const h16x8* pl = ph + 18 * 2 * C2;
 #pragma unroll
         for (int st = 0; st < 18; ++st) {
             wh[st] = ph[st * 2 * C2];
@@ -272,21 +264,22 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
     }
     float bias = b2[i];
     asm volatile("" : "+v"(bias));         // (settled here: a load still "pending" at the loop head costs a vmcnt wait in front of every store)
+    const float c2 = S.c2;
     // W1^T as the A operand: row = channel i, k = tap (0..8), 9 = bias (times a constant 1), 10..15 = 0
-    bf16x8 w1h, w1l;
+    h16x8 w1h, w1l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int tap = 8 * h + j;
-        const float v = tap < 9 ? w1[(tap < 9 ? tap : 0) * C1 + i] : tap == 9 ? b1[i] : 0.f;
-        const __bf16 vh = (__bf16)v;
+        const float v = (tap < 9 ? w1[(tap < 9 ? tap : 0) * C1 + i] : tap == 9 ? b1[i] : 0.f) * S.sa2;   // conv1 writes conv2's scaled inputs
+        const _Float16 vh = (_Float16)v;
         w1h[j] = vh;
-        w1l[j] = (__bf16)(v - (float)vh);
+        w1l[j] = (_Float16)(v - (float)vh);
     }
     // (fetched from LDS for every pixel block: eight registers that do not have to live through the matrix loop)
     unsigned char* const ldsW1 = ldsP + 2 * P12_BUF + lane * 16;
     if (wave == 0) {
-        *reinterpret_cast<bf16x8*>(ldsW1) = w1h;
-        *reinterpret_cast<bf16x8*>(ldsW1 + 64 * 16) = w1l;
+        *reinterpret_cast<h16x8*>(ldsW1) = w1h;
+        *reinterpret_cast<h16x8*>(ldsW1 + 64 * 16) = w1l;
     }
 
     // conv2: this lane's pixel (accumulator row i): image row 2 rp + (i >> 4), column 16 ch + (i & 15)
@@ -340,7 +333,7 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
     // conv1 of pixel block tt of task t_(k+1), stage c: 0 taps from LDS, 1 split, 2 the three MFMAs, 3 .. 6 ReLU + split + store of
     // channels 8 g + 4 h .. + 3 (g = c - 3)
     float xv[8];
-    bf16x8 xh, xl;
+    h16x8 xh, xl;
     f32x16 a1;
     u32x2 kh, kl;
     auto conv1_stage = [&](int k, int tt, int c) {
@@ -353,13 +346,13 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
 #pragma unroll
             for (int j = 1; j < 8; ++j) xv[j] = x1p[(j / 3) * XW + (j % 3)];
         } else if (c == 1) {
-            w1h = *reinterpret_cast<const bf16x8*>(ldsW1);
-            w1l = *reinterpret_cast<const bf16x8*>(ldsW1 + 64 * 16);
+            w1h = *reinterpret_cast<const h16x8*>(ldsW1);
+            w1l = *reinterpret_cast<const h16x8*>(ldsW1 + 64 * 16);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const __bf16 vh = (__bf16)xv[j];
+                const _Float16 vh = (_Float16)xv[j];
                 xh[j] = vh;
-                xl[j] = (__bf16)(xv[j] - (float)vh);
+                xl[j] = (_Float16)(xv[j] - (float)vh);
             }
         } else if (c == 2) {
 #pragma unroll
@@ -373,7 +366,7 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
             // lane (i, 1) chunk 1 whole - one 16-byte store per lane, plane and piece instead of two 8-byte stores with a
             // 32-byte lane stride (four-way bank conflicts: 37 % of the kernel's LDS cycles)
             const int g = c - 3;
-            bf16x4 vh, vl;
+            h16x4 vh, vl;
             split4(relu(a1[4 * g]), relu(a1[4 * g + 1]), relu(a1[4 * g + 2]), relu(a1[4 * g + 3]), vh, vl);
             const u32x2 bh = __builtin_bit_cast(u32x2, vh), bl = __builtin_bit_cast(u32x2, vl);
             if ((g & 1) == 0) {
@@ -412,14 +405,14 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
         unsigned win, xi0;
         tile_split(blockIdx.x + (unsigned)k * G, xt, win, xi0);
         const int x0 = 32 * (int)xi0 + 16 * ch;
-        __bf16* o = out + ((size_t)(win * 4 + rp) * (size_t)Wa + (size_t)((x0 >> 1) + 2 * h)) * 64 + i;
+        _Float16* o = out + ((size_t)(win * 4 + rp) * (size_t)Wa + (size_t)((x0 >> 1) + 2 * h)) * 64 + i;
 #pragma unroll
         for (int kk = kk0; kk < kk0 + 2; ++kk) {
             const int q = 2 * kk;
             const int dpx = ((q & 3) + 8 * (q >> 2)) >> 1;                     // 0, 1, 4, 5
-            const float v = relu(pm[kk] + bias);
-            const __bf16 vh = (__bf16)v;
-            const __bf16 vl = (__bf16)(v - (float)vh);
+            const float v = relu(fmaf(pm[kk], c2, bias));
+            const _Float16 vh = (_Float16)v;
+            const _Float16 vl = (_Float16)(v - (float)vh);
             o[dpx * 64] = vh;
             o[dpx * 64 + 32] = vl;
         }
@@ -505,10 +498,12 @@ constexpr int BIAS3_BYTES = 2 * 2 * 16 * 4;        // conv3 biases in accumulato
 constexpr size_t LDS34 = 2 * (size_t)PA_BUF + 2 * (size_t)PB_BUF + 2 * (size_t)X_BUF + BIAS3_BYTES;
 static_assert(LDS34 <= 160 * 1024, "one workgroup per CU");
 
-__global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in, const bf16x8* __restrict__ w3s,
-                                                   const float* __restrict__ b3, const bf16x8* __restrict__ w4s,
+__global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in, const h16x8* __restrict__ w3s,
+                                                   const float* __restrict__ b3, const h16x8* __restrict__ w4s,
                                                    const float* __restrict__ b4, float* __restrict__ out,
-                                                   const uint4* __restrict__ zeros, int Win, int Wa, tile_div xt, unsigned ntile WS_STAMP_ARG) {
+                                                   const uint4* __restrict__ zeros, int Win, int Wa, tile_div xt, unsigned ntile,
+                                                   f2_split_scales S WS_STAMP_ARG) {
+    // (b3 = conv3's biases x sa_3 sb_3: the accumulators start from them; b4 = conv4's x sa_dense1; out x sa_dense1)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + 2 * PA_BUF;
@@ -528,10 +523,10 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
     if (wave < 4) {
         // ---------------- conv3: output tile nt (32 of the 64 channels), rows 2 rp, 2 rp + 1 ----------------
         const int nt = wave & 1, rp = wave >> 1;
-        bf16x8 wh[18], wl[18];
+        h16x8 wh[18], wl[18];
         {
-            const bf16x8* ph = w3s + h * C3 + nt * 32 + i;    // [piece][tap][kb][h][cout]
-            const bf16x8* pl = ph + 18 * 2 * C3;
+            const h16x8* ph = w3s + h * C3 + nt * 32 + i;    // [piece][tap][kb][h][cout]
+            const h16x8* pl = ph + 18 * 2 * C3;
 #pragma unroll
             for (int st = 0; st < 18; ++st) {
                 wh[st] = ph[st * 2 * C3];
@@ -544,6 +539,7 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
             }
         }
         const f32x4* bias4 = reinterpret_cast<const f32x4*>(ldsBias + (nt * 2 + h) * 16);   // (16 registers too many to hold)
+        const float c3 = S.c3;
         // LDS-DMA pieces of this wave, once: 16-byte slot s = 64 piece + lane of a patch A buffer = (piece, pixel, position) <-
         // chunk (position ^ swizzle(pixel)) of that pixel's piece (the XOR is its own inverse: the readers apply the same one).
         // rel = the chunk's index relative to (window, column c0 - 1) of the input; pcx = the pixel's patch column, or a value no
@@ -596,11 +592,12 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
                 auto epilogue = [&](int mt, int g) {
                     const int pb = (2 * rp + mt) * PW + i;
                     const int base = b64_off(pb, 2 * nt) + 8 * h;   // chunk 2 nt + (g & 1) of plane g >> 1: base ^ ((g & 1) << 4)
-                    bf16x4 vh, vl;
-                    split4(relu(acc[mt][4 * g]), relu(acc[mt][4 * g + 1]), relu(acc[mt][4 * g + 2]), relu(acc[mt][4 * g + 3]), vh, vl);
+                    h16x4 vh, vl;
+                    split4(relu(acc[mt][4 * g]) * c3, relu(acc[mt][4 * g + 1]) * c3, relu(acc[mt][4 * g + 2]) * c3,
+                           relu(acc[mt][4 * g + 3]) * c3, vh, vl);
                     const int off = (g >> 1) * PB_PLANE + (base ^ ((g & 1) << 4));
-                    *reinterpret_cast<bf16x4*>(pbh + off) = vh;
-                    *reinterpret_cast<bf16x4*>(pbh + PB_PIECE + off) = vl;
+                    *reinterpret_cast<h16x4*>(pbh + off) = vh;
+                    *reinterpret_cast<h16x4*>(pbh + PB_PIECE + off) = vl;
                 };
                 PRIO_MATRIX();
                 // behind the fragments of the matrix loop: the LDS-DMA pieces (first: they have the whole iteration to land) and,
@@ -626,10 +623,10 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
     } else {
         // ---------------- loader + conv4: output tile nt, K half kh (input channels 32 kh .. 32 kh + 31) ----------------
         const int cw = wave - 4, nt = cw & 1, kh = cw >> 1;
-        bf16x8 wh[18], wl[18];
+        h16x8 wh[18], wl[18];
         {
-            const bf16x8* ph = w4s + h * C4 + nt * 32 + i;    // [piece][tap][kb (4)][h][cout]
-            const bf16x8* pl = ph + 36 * 2 * C4;
+            const h16x8* ph = w4s + h * C4 + nt * 32 + i;    // [piece][tap][kb (4)][h][cout]
+            const h16x8* pl = ph + 36 * 2 * C4;
 #pragma unroll
             for (int st = 0; st < 18; ++st) {
                 const int it = (st >> 1) * 4 + 2 * kh + (st & 1);
@@ -644,6 +641,7 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
         }
         float bias = b4[nt * 32 + i];
         asm volatile("" : "+v"(bias));     // (settled here: see k_conv12_ws)
+        const float c4 = S.c4;
         f32x16 acc[2];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -674,7 +672,7 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
                     const int xl = (q & 3) + 8 * (q >> 2) + 4 * h;    // even conv4 column inside the tile
                     const int pxp = (c0 + xl) >> 1;
                     const float m = fmaxf(fmaxf(acc[0][q], acc[0][q + 1]), fmaxf(acc[1][q], acc[1][q + 1]));
-                    if (xl < T34 && pxp < Wp) o[pxp * C4] = relu(m + bias);
+                    if (xl < T34 && pxp < Wp) o[pxp * C4] = relu(fmaf(m, c4, bias));
                 }
             }
             WS_STAMP(j, 4);
@@ -710,7 +708,7 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
 // ------------------------------------------------------------------------------------------------------------------
 // dense1 from pre-split activations
 // ------------------------------------------------------------------------------------------------------------------
-// out (n, D1) = ReLU(a (n, K) W (K, D1) + b). k_dense1_bf16x3 (f2_cnn.hip) streams 2 KB of split weights per wave and K step for 6
+// out (n, D1) = ReLU(a (n, K) W (K, D1) + b). k_dense1_h16x3 (f2_cnn.hip) streams 2 KB of split weights per wave and K step for 6
 // MFMAs (64 windows per workgroup) and lets the compiler place the waits of its prefetched loads: vmcnt(0) at the head of every
 // chunk, the fragment requested a moment ago included. Here a weight fragment feeds 3 MT MFMAs (MT = 3: 96 windows), every
 // global load of the K loop is issued and waited for by hand (two K steps ahead for the weights, a chunk ahead for the
@@ -721,9 +719,9 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
 // takes 18 us out of this kernel's staging and puts them into k_conv34_ws's combine, which runs beside matrix loops.)
 constexpr int D1W_WAVES = 6, D1W_KC = 64, D1W_TILES = 17, D1W_NPAD = D1W_TILES * 32, D1W_N = 516;
 template <int MT>
-__global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __restrict__ a, const bf16x8* __restrict__ ws,
+__global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __restrict__ a, const h16x8* __restrict__ ws,
                                                                  const float* __restrict__ bias, float* __restrict__ out, int K,
-                                                                 int64_t n) {
+                                                                 int64_t n, f2_split_scales S) {
     constexpr int ROWS = 32 * MT, PIECE = ROWS * 128, BUF = 2 * PIECE;
     static_assert(2 * BUF <= 80 * 1024 && 2 * BUF - 1 + 0 < 65536, "two workgroups per CU; immediate ds offsets");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -734,8 +732,8 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
     const int nt = blockIdx.y * D1W_WAVES + wave;
     const bool live = nt < D1W_TILES;
     const int ntc = live ? nt : D1W_TILES - 1;                       // (idle waves load a valid tile and discard it)
-    const bf16x8* wh = ws + (int64_t)h * D1W_NPAD + ntc * 32 + i;    // w[piece][chunk][ks][h][n (544)][8]
-    const bf16x8* wl = wh + (int64_t)nchunks * 4 * 2 * D1W_NPAD;
+    const h16x8* wh = ws + (int64_t)h * D1W_NPAD + ntc * 32 + i;    // w[piece][chunk][ks][h][n (544)][8]
+    const h16x8* wl = wh + (int64_t)nchunks * 4 * 2 * D1W_NPAD;
 
     // Staging: thread slot s = tid + 384 m = (row, chunk c of eight K values): two 16-byte loads (eight float32), split, two
     // 16-byte LDS stores (hi and lo chunk) at position c ^ ((row >> 1) & 7) of the row in either piece; rows
@@ -769,12 +767,12 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
 #pragma unroll
         for (int m = 0; m < PERT; ++m) {
             const f32x4 x = __builtin_bit_cast(f32x4, ar[2 * m]), y = __builtin_bit_cast(f32x4, ar[2 * m + 1]);
-            bf16x4 h0, l0, h1, l1;
+            h16x4 h0, l0, h1, l1;
             split4(x[0], x[1], x[2], x[3], h0, l0);
             split4(y[0], y[1], y[2], y[3], h1, l1);
             if (dstoff[m] >= 0) {
-                *reinterpret_cast<bf16x8*>(lds + buf * BUF + dstoff[m]) = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                *reinterpret_cast<bf16x8*>(lds + buf * BUF + PIECE + dstoff[m]) = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                *reinterpret_cast<h16x8*>(lds + buf * BUF + dstoff[m]) = h16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                *reinterpret_cast<h16x8*>(lds + buf * BUF + PIECE + dstoff[m]) = h16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
             }
         }
     };
@@ -798,15 +796,15 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
 #define D1W_WAIT(N, slot) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bh[slot]), "+v"(bl[slot])::"memory")
     auto step_mfmas = [&](const unsigned char* pa, int ks) {
         // activations one M tile ahead of the MFMAs that use them
-        const bf16x8 wb_h = __builtin_bit_cast(bf16x8, bh[ks]), wb_l = __builtin_bit_cast(bf16x8, bl[ks]);
-        bf16x8 ah[2], al[2];
-        ah[0] = *reinterpret_cast<const bf16x8*>(pa + aoff[ks]);
-        al[0] = *reinterpret_cast<const bf16x8*>(pa + aoff[ks] + PIECE);
+        const h16x8 wb_h = __builtin_bit_cast(h16x8, bh[ks]), wb_l = __builtin_bit_cast(h16x8, bl[ks]);
+        h16x8 ah[2], al[2];
+        ah[0] = *reinterpret_cast<const h16x8*>(pa + aoff[ks]);
+        al[0] = *reinterpret_cast<const h16x8*>(pa + aoff[ks] + PIECE);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             if (t + 1 < MT) {
-                ah[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(pa + aoff[ks] + (t + 1) * 4096);
-                al[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(pa + aoff[ks] + (t + 1) * 4096 + PIECE);
+                ah[(t + 1) & 1] = *reinterpret_cast<const h16x8*>(pa + aoff[ks] + (t + 1) * 4096);
+                al[(t + 1) & 1] = *reinterpret_cast<const h16x8*>(pa + aoff[ks] + (t + 1) * 4096 + PIECE);
             }
             acc[t] = MFMA16(al[t & 1], wb_h, acc[t]);
             acc[t] = MFMA16(ah[t & 1], wb_l, acc[t]);
@@ -878,14 +876,14 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int64_t wr = w0 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (wr < n) out[wr * D1W_N + col] = relu(acc[t][q] + b);
+                if (wr < n) out[wr * D1W_N + col] = relu(fmaf(acc[t][q], S.cd, b));
             }
     }
 }
 
 }  // namespace
 
-// conv1 .. conv4 + pools of n windows: x (n, H1, W1) float32 -> a2s (n, 4, W1/2 - 1, [hi 32 | lo 32]) bf16 (scratch) ->
+// conv1 .. conv4 + pools of n windows: x (n, H1, W1) float32 -> a2s (n, 4, W1/2 - 1, [hi 32 | lo 32]) fp16, x sa_3 (scratch) ->
 // a4 (n, 1, Wp2, 64) float32. Only for windows with four pooled rows after conv2 (f2_cnn_ws_supported).
 bool f2_cnn_ws_supported(int rows, int channels) {
     const int Hp1 = (rows - 2) / 2, Wp1 = (channels - 2) / 2;
@@ -949,8 +947,8 @@ int f2_launch_cnn_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n
         F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv12_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS12));
         const unsigned grid = (unsigned)(ntask < grid_max ? ntask : grid_max);
         hipLaunchKernelGGL(k_conv12_ws, dim3(grid), dim3(512), LDS12, ctx->stream, d_x, cnn->t(0), cnn->t(1),
-                           (const bf16x8*)(cnn->blob16 + cnn->off16[0]), cnn->t(3), (__bf16*)a2s, (const float*)cnn->zeros, H1, W1,
-                           Wa, xt, (unsigned)ntask WS_STAMP_PASS);
+                           (const h16x8*)(cnn->blob16 + cnn->off16[0]), cnn->sbias + F2_SB_B2, (_Float16*)a2s, (const float*)cnn->zeros, H1, W1,
+                           Wa, xt, (unsigned)ntask, cnn->sc WS_STAMP_PASS);
         F2_HIP(ctx, hipGetLastError());
 #ifdef F2_WS_STAMPS
         ws_stamp_report(ctx, "k_conv12_ws (slot4 / slot5 = VALU phase of waves 4-7 / 0-3 done)", d_stamps);
@@ -965,8 +963,8 @@ int f2_launch_cnn_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* d_x, int64_t n
         F2_HIP(ctx, hipFuncSetAttribute((const void*)k_conv34_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS34));
         const unsigned grid = (unsigned)(ntile < grid_max ? ntile : grid_max);
         hipLaunchKernelGGL(k_conv34_ws, dim3(grid), dim3(512), LDS34, ctx->stream, (const uint4*)a2s,
-                           (const bf16x8*)(cnn->blob16 + cnn->off16[1]), cnn->t(5), (const bf16x8*)(cnn->blob16 + cnn->off16[2]),
-                           cnn->t(7), a4, (const uint4*)cnn->zeros, Wp1, Wa, xt, (unsigned)ntile WS_STAMP_PASS);
+                           (const h16x8*)(cnn->blob16 + cnn->off16[1]), cnn->sbias + F2_SB_B3I, (const h16x8*)(cnn->blob16 + cnn->off16[2]),
+                           cnn->sbias + F2_SB_B4, a4, (const uint4*)cnn->zeros, Wp1, Wa, xt, (unsigned)ntile, cnn->sc WS_STAMP_PASS);
         F2_HIP(ctx, hipGetLastError());
 #ifdef F2_WS_STAMPS
         ws_stamp_report(ctx, "k_conv34_ws (waves 0-3 conv3; 4-7 conv4: slot4 = K halves combined + stored, slot5 = LDS-DMA issued)", d_stamps);
@@ -987,7 +985,7 @@ int f2_launch_dense1_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t
     F2_HIP(ctx, hipFuncSetAttribute((const void*)k_dense1_ws<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     const dim3 grid((unsigned)((n + 32 * MT - 1) / (32 * MT)), (D1W_TILES + D1W_WAVES - 1) / D1W_WAVES);
     hipLaunchKernelGGL(k_dense1_ws<MT>, grid, dim3(D1W_WAVES * 64), LDSB, ctx->stream, a4,
-                       (const bf16x8*)(cnn->blob16 + cnn->off16[3]), cnn->t(9), a5, K, n);
+                       (const h16x8*)(cnn->blob16 + cnn->off16[3]), cnn->t(9), a5, K, n, cnn->sc);
     F2_HIP(ctx, hipGetLastError());
     return F2_OK;
 }

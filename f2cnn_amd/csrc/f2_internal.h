@@ -92,7 +92,7 @@ struct f2_ctx {
     int opt_k1_queue = -1;                // unit queue of the filterbank for ragged batches (0 / 1)
     int opt_k1_qwaves = 0;                // waves of the queue launch (0 = from the batch)
     int opt_env_pair = 1;                 // on-chip kernel for rows of 32769..65536 samples
-    int opt_cnn_bf16x3 = 1;               // conv3 + conv4 on the bf16 matrix cores, operands split in two pieces (3 MFMAs per product)
+    int opt_cnn_bf16x3 = 1;               // conv2 .. conv4 + dense1 on the fp16 matrix cores, operands split in two pieces (3 MFMAs per product; "cnn_f16x3")
     int opt_cnn_ws = 1;                   // ... with the weights of each wave's role held in registers (f2_cnn_ws.hip; windows of 10 / 11 rows)
     int opt_cnn_ws_dense = 1;             // ... and dense1 with 96 windows per weight fragment, loads waited for by hand (k_dense1_ws)
     int opt_gather_blocked = 1;           // every-sample windows: logarithm once per sample, blocks of 32 windows (0: one workgroup per window)
@@ -117,13 +117,21 @@ struct f2_ctx {
     int* host_flags = nullptr;  // pinned mirror
 };
 
+#include "f2_cnn_split.h"
+// offsets (floats) into f2_cnn::sbias: conv2's biases x sa_3; conv3's x sa_3 sb_3 (accumulator-initial form) and x sa_4 (epilogue
+// form); conv4's x sa_dense1
+enum { F2_SB_B2 = 0, F2_SB_B3I = 64, F2_SB_B3F = 128, F2_SB_B4 = 192, F2_SB_FLOATS = 256 };
+
 struct f2_cnn {
     int rows = 0, channels = 0, flat = 0;
     int dev = 0;
     float* blob = nullptr;       // all tensors, device
     size_t off[12] = {0};        // element offsets of the 12 tensors in `blob`
     const float* t(int i) const { return blob + off[i]; }
-    uint16_t* blob16 = nullptr;  // conv2 .. conv4 and dense1 kernels split into two bf16 pieces (f2_cnn.hip, k_*_bf16x3)
+    uint16_t* blob16 = nullptr;  // conv2 .. conv4 and dense1 kernels, scaled and split into two fp16 pieces (f2_cnn_split.h, k_*_h16x3)
+    f2_split_scales sc = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // the power-of-two scales that go with them
+    float c2_true = 1.f, sa_d1 = 1.f;   // 1 / (sa_2 sb_2): conv2's epilogue multiplier for outputs in true units; dense1's input scale
+    float* sbias = nullptr;      // biases in the scaled units the split kernels' epilogues use (F2_SB_* offsets)
     size_t off16[4] = {0};       // element offsets of the four layers in `blob16`
     const void* zeros = nullptr; // 256 zero bytes behind them (source of the padding pixels of f2_cnn_ws.hip's LDS-DMA loads)
     // f2_cnn_create's self-check of the weight-stationary kernels (hand-placed s_waitcnt around inline-asm loads: correct only

@@ -153,7 +153,7 @@ constexpr size_t lowpass_tab_lds_bytes() {
 // (q^2)^((lane & 31) + 1)}. All threads call it, after a barrier that makes `smem` free.
 // CHAINED (rows longer than one sweep of the workgroup, k_spectral_envelope_long): the pairs are those of the samples from
 // `ibase` on, e_in = e[ibase - 1], *ychain = y[ibase - 1] on entry and y[ibase + 2 NT NBLK - 1] on return.
-// Returns this thread's maximum of |y| over the samples it stored (the accuracy guard's denominator when the low-pass is on).
+// Returns this thread's maximum of |y| over the odd samples it stored (the accuracy guard's denominator when the low-pass is on).
 template <int NT, int NBLK, bool CHAINED = false>
 __device__ __forceinline__ float lowpass_pairs_store_tab(const float (&er)[NBLK], const float (&ei)[NBLK], const LowpassConsts& K,
                                                         const f2_f4* __restrict__ lptab, unsigned char* smem,
@@ -237,10 +237,11 @@ __device__ __forceinline__ float lowpass_pairs_store_tab(const float (&er)[NBLK]
         const float y1 = fmaf(K.qf, y0, u1[jj]);
         const int i0 = ibase + 2 * (tid + NT * jj);
         store_row_pair_buf(yb, n, i0, (double)y0, (double)y1);
-        // (block boundaries are wave-uniform: only the block that holds sample n - 1 masks per lane)
+        // every second output sample is enough for the maximum of a low-passed row (it only scales the guard's threshold);
+        // block boundaries are wave-uniform: only the block that holds sample n - 1 masks per lane
         const int lo = ibase + 2 * NT * jj;
-        if (lo + 2 * NT <= n) ymax = fmaxf(ymax, fmaxf(fabsf(y0), fabsf(y1)));
-        else if (lo < n) ymax = fmaxf(ymax, fmaxf(i0 < n ? fabsf(y0) : 0.f, i0 + 1 < n ? fabsf(y1) : 0.f));
+        if (lo + 2 * NT <= n) ymax = fmaxf(ymax, fabsf(y1));
+        else if (lo < n) ymax = fmaxf(ymax, i0 + 1 < n ? fabsf(y1) : fabsf(y0));
     }
     return ymax;
 }
@@ -360,7 +361,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     constexpr int TWL = plan_tw_lds_count(LOG2H);
     __shared__ __attribute__((aligned(16))) cpx<float> twl[TWL > 0 ? TWL : 1];
-    __shared__ unsigned guard[3];   // max |a| inside [0, n) / Re a inside [n, M) / low-passed row maximum, as float bits (>= 0)
+    __shared__ unsigned guard[4];   // max |a| inside [0, n) / Re a inside [n, M) / low-passed row maximum, as float bits (>= 0); waves counted in
     cpx<float>* lds = reinterpret_cast<cpx<float>*>(smem);
 
     const int tid = threadIdx.x;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
 #endif
     F2_SSTAMP(0);
     for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2H, 1) + i];
-    if (tid < 3) guard[tid] = 0u;
+    if (tid < 4) guard[tid] = 0u;
 
     // 1. spectrum of the zero-padded row at this thread's bins k = tid + j NB0 (first-pass register layout). Per bin two
     //    loads (utterance spectrum, channel table); the two phase factors follow from one load each: w_k = w_tid e^{-2 pi i
@@ -525,12 +526,9 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     }
     gin = wave_max63(gin);
     gout = wave_max63(gout);
-    if ((tid & 63) == 63) {
-        atomicMax(&guard[0], __float_as_uint(gin));
-        atomicMax(&guard[1], __float_as_uint(gout));
-    }
     F2_SSTAMP(6);
     // 5. stores (the last pass of the transform ended with a barrier after its LDS reads: smem is free)
+    float glp = 0.f;
     if (!P.lpf) {
         const __amdgpu_buffer_rsrc_t yb = row_buffer(y, n);
 #pragma unroll
@@ -538,12 +536,17 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     } else {
         // the parity bar is written on the LOW-PASSED row (EnvelopeExtraction.py:57-66): its maximum, which a bursty row
         // keeps several times below the raw one, is what the residual is compared with
-        float glp = lowpass_pairs_store_tab<NT, NBLK>(er, ei, P.lp, lptab, smem, y, n, tid);   // (contains barriers)
-        glp = wave_max63(glp);
-        if ((tid & 63) == 63) atomicMax(&guard[2], __float_as_uint(glp));
+        glp = wave_max63(lowpass_pairs_store_tab<NT, NBLK>(er, ei, P.lp, lptab, smem, y, n, tid));   // (contains barriers)
     }
-    __syncthreads();
-    if (tid == 0) guard_decide(P, guard, b, c);
+    // No barrier for the verdict: every wave posts its three maxima and then counts itself in; the LDS serves a wave's
+    // operations in order, so the wave that counts in last sees everybody's maxima and decides for the row.
+    if ((tid & 63) == 63) {
+        __hip_atomic_fetch_max(&guard[0], __float_as_uint(gin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&guard[1], __float_as_uint(gout), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&guard[2], __float_as_uint(glp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__hip_atomic_fetch_add(&guard[3], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(NT / 64 - 1))
+            guard_decide(P, guard, b, c);
+    }
 #ifdef F2_STAMPS
     F2_SSTAMP(7);
     if (tid == 0 && P.stamps)
