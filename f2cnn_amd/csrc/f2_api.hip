@@ -749,10 +749,13 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
                 F2_HIP(ctx, hipMemsetAsync(ctx->spec_gdump.ptr, 0xff, gbytes, ctx->stream));
                 ctx->spec_gdump_rows = (size_t)B * (size_t)C;
             }
-            for (int l = F2_SPECTRAL_MIN_LOG2H; l <= F2_SPECTRAL_MAX_LOG2H; ++l)
+            for (int l = F2_SPECTRAL_MIN_LOG2H; l <= F2_SPECTRAL_MAX_LOG2H; ++l) {
+                int64_t min_n = INT64_MAX;
+                for (int b : lists[l]) min_n = std::min(min_n, offsets[b + 1] - offsets[b]);
                 F2_TRY(f2_launch_spectral(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, (const double*)ctx->coefs.ptr,
-                                          C, (const int*)ctx->spec_meta.ptr + pos[l], (int)lists[l].size(), l, lpf, cutoff_hz,
-                                          d_env, uflag));
+                                          C, (const int*)ctx->spec_meta.ptr + pos[l], (int)lists[l].size(), min_n, l, lpf,
+                                          cutoff_hz, d_env, uflag));
+            }
             d_uflag = uflag;
             ctx->spec_last_B = (size_t)B;
         }

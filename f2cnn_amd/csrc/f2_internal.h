@@ -246,7 +246,8 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
 bool f2_spectral_supports_len(int64_t n, int min_pad);
 bool f2_spectral_supports_coefs(const std::vector<double>& coefs, int C, std::vector<int>* Lgroup, int* min_pad);
 int f2_launch_spectral(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets, const double* d_coefs,
-                       int C, const int* d_ulist, int nutt, int log2h, int lpf, double cutoff_hz, double* d_env, int* d_uflag);
+                       int C, const int* d_ulist, int nutt, int64_t min_n /* shortest row of the group */, int log2h, int lpf,
+                       double cutoff_hz, double* d_env, int* d_uflag);
 // d_centers == NULL: window e is centred at first_center + e
 int f2_launch_gather(f2_ctx* ctx, const double* d_env, int C, int64_t N, const int64_t* d_centers,
                      int64_t first_center, int64_t n_windows, int radius, int step, int normalize, float* d_out, int* d_flag);

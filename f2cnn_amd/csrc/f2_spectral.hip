@@ -299,28 +299,49 @@ __device__ __forceinline__ cpx<float> bin_w(cpx<float> w0, int j) {
     }
 }
 
-// maximum over the wave, result valid in lane 63 (row_shr 1/2/4/8, row_bcast 15/31; values >= 0, missing lanes read 0)
+// maximum over the wave of non-negative values (two at once: independent chains), results valid in lane 63: row_shr 1/2/4/8, row_bcast 15/31,
+// every step ONE v_max_f32 with the lane move as its operand (the compiler leaves v_mov_b32_dpp + v_max_f32 pairs; lanes
+// without a source lane read 0, rows outside the mask keep their value)
+#define F2_DPP_MAX2(CTRL)                                              \
+    asm volatile("s_nop 1\n\t"                                         \
+                 "v_max_f32_dpp %0, %0, %0 " CTRL "\n\t"               \
+                 "v_max_f32_dpp %1, %1, %1 " CTRL                       \
+                 : "+v"(a), "+v"(b))
+__device__ __forceinline__ void wave_max63x2(float& a, float& b) {
+    F2_DPP_MAX2("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    F2_DPP_MAX2("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    F2_DPP_MAX2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    F2_DPP_MAX2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    F2_DPP_MAX2("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    F2_DPP_MAX2("row_bcast:31 row_mask:0xc bank_mask:0xf");
+}
 __device__ __forceinline__ float wave_max63(float v) {
-    v = fmaxf(v, dpp_mov<0x111, 0xF>(v));
-    v = fmaxf(v, dpp_mov<0x112, 0xF>(v));
-    v = fmaxf(v, dpp_mov<0x114, 0xF>(v));
-    v = fmaxf(v, dpp_mov<0x118, 0xF>(v));
-    v = fmaxf(v, dpp_mov<0x142, 0xA>(v));
-    v = fmaxf(v, dpp_mov<0x143, 0xC>(v));
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
     return v;
 }
 
-// max |Re a| over this thread's samples in the padding region [n, M): v[brev(j)] = sample 2 (tid + NT j) + odd. One
-// wave-uniform branch: rows whose padding lies in the last block only (every 1 s row of a 16384-point class) look at one value.
-template <int R0, int NT>
+// max |Re a| over this thread's samples in the padding region [n, M): v[brev(j)] = sample 2 (tid + NT j) + odd.
+// PADLAST: every row of the launch has its padding inside the last block (n >= 15/16 M: every 1 s row of a 16384-point class).
+template <int R0, int NT, bool PADLAST>
 __device__ __forceinline__ float pad_residual(const cpx<float> (&v)[R0], int n, int tid, int odd, float gout) {
-    // sample 2 (tid + NT j) + odd >= n  <=>  j >= jmin (one register; the compiler would otherwise keep sixteen sample indices)
-    int jmin = (n - 2 * tid - odd + 2 * NT - 1) >> (__builtin_ctz(2 * NT));
-    asm volatile("" : "+v"(jmin));
-    // (rows of this length class have n > M / 2: the first half of the blocks never holds padding)
+    if constexpr (PADLAST) {
+        return fmaxf(gout, 2 * (tid + NT * (R0 - 1)) + odd >= n ? fabsf(v[brev<R0>(R0 - 1)].re) : 0.f);
+    } else {
+        // sample 2 (tid + NT j) + odd >= n  <=>  j >= jmin (one register; the compiler would otherwise keep sixteen sample indices)
+        int jmin = (n - 2 * tid - odd + 2 * NT - 1) >> (__builtin_ctz(2 * NT));
+        asm volatile("" : "+v"(jmin));
+        // (rows of this length class have n > M / 2: the first half of the blocks never holds padding)
 #pragma unroll
-    for (int j = R0 / 2; j < R0; ++j) gout = fmaxf(gout, j >= jmin ? fabsf(v[brev<R0>(j)].re) : 0.f);
-    return gout;
+        for (int j = R0 / 2; j < R0; ++j) gout = fmaxf(gout, j >= jmin ? fabsf(v[brev<R0>(j)].re) : 0.f);
+        return gout;
+    }
 }
 
 // one thread per row, after the barrier behind the last atomicMax: flag the utterance if the padding-region residual exceeds
@@ -339,7 +360,7 @@ __device__ __forceinline__ void guard_decide(const SpecParams& P, const unsigned
     }
 }
 
-template <int LOG2H>
+template <int LOG2H, bool PADLAST>
 __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float, LOG2H>())) void k_spectral_envelope(
     SpecParams P, const cpx<float>* __restrict__ Xall /* utterance spectra */, const f2_f4* __restrict__ HUall,
     const cpx<float>* __restrict__ E /* [M] exp(-2 pi i q / M) */, const float* __restrict__ rho_all /* [rows][8] digits of Q */,
@@ -499,7 +520,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         asm volatile("" : "+v"(tid_e), "+v"(v[0].re), "+v"(vo[PT - 1].im));
         fft_pass0_pair<LOG2H, NT, PT>(tw, tid_e, v, vo);
         fft_from_pass0<LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, v);
-        gout = pad_residual<R0, NT>(v, n, tid, 0, gout);
+        gout = pad_residual<R0, NT, PADLAST>(v, n, tid, 0, gout);
 #pragma unroll
         for (int j = 0; j < R0; ++j) {
             const cpx<float> a = v[brev<R0>(j)];
@@ -507,7 +528,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         }
         fft_from_pass0<LOG2H, PT, NT, T0R>(lds, tw, twl, tid_e, vo);
         F2_SSTAMP(5);
-        gout = pad_residual<R0, NT>(vo, n, tid, 1, gout);
+        gout = pad_residual<R0, NT, PADLAST>(vo, n, tid, 1, gout);
 #pragma unroll
         for (int j = 0; j < R0; ++j) {
             const cpx<float> a = vo[brev<R0>(j)];
@@ -524,11 +545,14 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
             gin = fmaxf(gin, fmaxf(i0 < n ? er[jj] : 0.f, i0 + 1 < n ? ei[jj] : 0.f));
         }
     }
-    gin = wave_max63(gin);
-    gout = wave_max63(gout);
+    float glp = 0.f;
+    wave_max63x2(gin, gout);
+    if ((tid & 63) == 63) {           // (posted here: they travel while the low-pass runs)
+        __hip_atomic_fetch_max(&guard[0], __float_as_uint(gin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&guard[1], __float_as_uint(gout), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     F2_SSTAMP(6);
     // 5. stores (the last pass of the transform ended with a barrier after its LDS reads: smem is free)
-    float glp = 0.f;
     if (!P.lpf) {
         const __amdgpu_buffer_rsrc_t yb = row_buffer(y, n);
 #pragma unroll
@@ -538,12 +562,10 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
         // keeps several times below the raw one, is what the residual is compared with
         glp = wave_max63(lowpass_pairs_store_tab<NT, NBLK>(er, ei, P.lp, lptab, smem, y, n, tid));   // (contains barriers)
     }
-    // No barrier for the verdict: every wave posts its three maxima and then counts itself in; the LDS serves a wave's
-    // operations in order, so the wave that counts in last sees everybody's maxima and decides for the row.
+    // No barrier for the verdict: every wave posts its maxima and then counts itself in; the LDS serves a wave's operations in
+    // order, so the wave that counts in last sees everybody's maxima and decides for the row.
     if ((tid & 63) == 63) {
-        __hip_atomic_fetch_max(&guard[0], __float_as_uint(gin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(&guard[1], __float_as_uint(gout), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(&guard[2], __float_as_uint(glp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (P.lpf) __hip_atomic_fetch_max(&guard[2], __float_as_uint(glp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (__hip_atomic_fetch_add(&guard[3], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(NT / 64 - 1))
             guard_decide(P, guard, b, c);
     }
@@ -1168,8 +1190,8 @@ static int lowpass_table(f2_ctx* ctx, double a1, double b0, int nt, int sp, Lowp
 
 template <typename WaveT, int LOG2H>
 static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offsets, const double* d_coefs, int C,
-                        const int* d_ulist, int nutt, int lpf, double b0, double a1, double* d_env, int* d_uflag, float tol,
-                        cpx<float>* d_X, float* d_rho) {
+                        const int* d_ulist, int nutt, int64_t min_n, int lpf, double b0, double a1, double* d_env, int* d_uflag,
+                        float tol, cpx<float>* d_X, float* d_rho) {
     constexpr int H = 1 << LOG2H, M = 2 * H;
     f2_spec_tables* tab = nullptr;
     F2_TRY(spectral_tables(ctx, d_coefs, C, LOG2H, &tab));
@@ -1227,8 +1249,12 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
         hipLaunchKernelGGL(k_spectral_envelope_long, dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, FFTLOG>()), 0,
                            ctx->stream, P, (const cpx<float>*)d_X, (const f2_f4*)tab->hu.ptr, (const cpx<float>*)tab->e.ptr,
                            (const float*)d_rho, d_offsets, d_ulist, d_lptab, (const cpx<float>*)ctx->tw_sp[0][FFTLOG].ptr);
+    else if (min_n >= 15 * (M / 16))    // every row's padding lies in the last block: the guard looks at that block only
+        hipLaunchKernelGGL((k_spectral_envelope<FFTLOG, true>), dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, FFTLOG>()), 0,
+                           ctx->stream, P, (const cpx<float>*)d_X, (const f2_f4*)tab->hu.ptr, (const cpx<float>*)tab->e.ptr,
+                           (const float*)d_rho, d_offsets, d_ulist, d_lptab, (const cpx<float>*)ctx->tw_sp[0][FFTLOG].ptr);
     else
-        hipLaunchKernelGGL((k_spectral_envelope<FFTLOG>), dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, FFTLOG>()), 0,
+        hipLaunchKernelGGL((k_spectral_envelope<FFTLOG, false>), dim3((unsigned)((size_t)nutt * C)), dim3(threads_for<float, FFTLOG>()), 0,
                            ctx->stream, P, (const cpx<float>*)d_X, (const f2_f4*)tab->hu.ptr, (const cpx<float>*)tab->e.ptr,
                            (const float*)d_rho, d_offsets, d_ulist, d_lptab, (const cpx<float>*)ctx->tw_sp[0][FFTLOG].ptr);
     F2_HIP(ctx, hipGetLastError());
@@ -1262,7 +1288,8 @@ static int launch_group(f2_ctx* ctx, const WaveT* d_wave, const int64_t* d_offse
 
 // Envelopes of the utterances `utts` (host list, all of length class log2h and eligible) straight from the waves.
 int f2_launch_spectral(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets, const double* d_coefs,
-                       int C, const int* d_ulist, int nutt, int log2h, int lpf, double cutoff_hz, double* d_env, int* d_uflag) {
+                       int C, const int* d_ulist, int nutt, int64_t min_n, int log2h, int lpf, double cutoff_hz, double* d_env,
+                       int* d_uflag) {
     if (nutt <= 0) return F2_OK;
     const double k = lpf ? tan(3.14159265358979323846 * cutoff_hz / 16000.0) : 0.0;
     const double b0 = k / (1.0 + k), a1 = (k - 1.0) / (k + 1.0);
@@ -1275,10 +1302,10 @@ int f2_launch_spectral(f2_ctx* ctx, const void* d_wave, int wave_dtype, const in
 #define F2_SPEC_CASE(L)                                                                                                          \
     case L:                                                                                                                      \
         return wave_dtype == F2_WAVE_I16                                                                                         \
-                   ? launch_group<int16_t, L>(ctx, (const int16_t*)d_wave, d_offsets, d_coefs, C, d_ulist, nutt, lpf, b0, a1,   \
-                                              d_env, d_uflag, tol, d_X, d_rho)                                                  \
-                   : launch_group<double, L>(ctx, (const double*)d_wave, d_offsets, d_coefs, C, d_ulist, nutt, lpf, b0, a1,      \
-                                             d_env, d_uflag, tol, d_X, d_rho);
+                   ? launch_group<int16_t, L>(ctx, (const int16_t*)d_wave, d_offsets, d_coefs, C, d_ulist, nutt, min_n, lpf, b0, \
+                                              a1, d_env, d_uflag, tol, d_X, d_rho)                                              \
+                   : launch_group<double, L>(ctx, (const double*)d_wave, d_offsets, d_coefs, C, d_ulist, nutt, min_n, lpf, b0,   \
+                                             a1, d_env, d_uflag, tol, d_X, d_rho);
     switch (log2h) {
         F2_SPEC_CASE(12)
         F2_SPEC_CASE(13)

@@ -13,7 +13,7 @@ F32_CYC = 2.0          # cycles per f32 VALU wave-instruction (SIMD-32)
 HBM_MIX, HBM_WR = 5.27e12, 6.2e12   # bytes/s: K2's read+write mix, pure writes (tools/ubench/stream_rw.hip)
 PEAK = 8e12
 KERNELS = (("K1", "k_erb_filterbank", "k_erb_filterbank"), ("K2", "k_envelope", "k_envelope<float, 13>"),
-           ("KS", "k_spectral_envelope", "k_spectral_envelope<13>"), ("KX", "k_utterance_spectrum", "k_utterance_spectrum"),
+           ("KS", "k_spectral_envelope", "k_spectral_envelope<13"), ("KX", "k_utterance_spectrum", "k_utterance_spectrum"),
            ("KT", "k_tail_state", "k_tail_state"))
 
 pmc = {}

@@ -23,8 +23,8 @@ corpus = int(sys.argv[4])
 lens = bench.ragged_lengths(2029, corpus)
 C = 128
 launches = max(1, -(-corpus // 2500))
-cls = {"k_spectral_envelope<13>": (lens > 8192) & (lens <= 16384), "k_spectral_envelope<14>": (lens > 16384) & (lens <= 32768),
-       "k_spectral_envelope_long": (lens > 32768) & (lens <= 65472)}
+cls = {"k_spectral_envelope<13": (lens > 8192) & (lens <= 16384 - 256), "k_spectral_envelope<14": (lens > 16384) & (lens <= 32768 - 256),
+       "k_spectral_envelope_long": (lens > 32768) & (lens <= 65536 - 256)}
 out = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --workload cfg5r; KiB per dispatch, mean over "
                  "dispatches; hbm bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction); rows = utterances of the class x 128 channels per launch",
        "workload": "cfg5r", "corpus": corpus, "launches_per_pass": launches, "lib_source_hash": bench.lib_source_hash()}

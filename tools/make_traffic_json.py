@@ -27,7 +27,7 @@ out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pa
                  "traffic of 17 MB of tables + 64 MB of spectra, not algorithmic bytes.",
        "workload": "cfg3", "batch": B, "lib_source_hash": bench.lib_source_hash()}
 names = {"k_erb_filterbank": "k_erb_filterbank", "k_envelope<float, 13>": "k_envelope",
-         "k_spectral_envelope<13>": "k_spectral_envelope", "k_utterance_spectrum": "k_utterance_spectrum", "k_tail_state": "k_tail_state"}
+         "k_spectral_envelope<13": "k_spectral_envelope", "k_utterance_spectrum": "k_utterance_spectrum", "k_tail_state": "k_tail_state"}
 # bytes each kernel MUST move: the spectral kernel writes the envelopes, its pre-kernels read the waves once each;
 # when the spectral route serves the whole batch the two-kernel launches only skip utterances (nothing required of them)
 spectral = any("k_spectral_envelope" in k for k in fetch)
