@@ -96,6 +96,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer_uniform(double* y, 
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     return row_buffer((double*)(((unsigned long long)hi << 32) | lo), __builtin_amdgcn_readfirstlane(n));
 }
+// envelope samples i0, i0 + 1, both known to lie inside the row
+__device__ __forceinline__ void store_row_pair_inside(__amdgpu_buffer_rsrc_t r, int i0, double a, double b) {
+    const f2_d2 v = {a, b};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(f2_u4, v), r, i0 * 8, 0, F2_KS_STORE_AUX);
+}
 // envelope samples i0, i0 + 1 of a row of n samples
 __device__ __forceinline__ void store_row_pair_buf(__amdgpu_buffer_rsrc_t r, int n, int i0, double a, double b) {
     if (i0 + 1 < n) {
@@ -154,7 +159,9 @@ constexpr size_t lowpass_tab_lds_bytes() {
 // CHAINED (rows longer than one sweep of the workgroup, k_spectral_envelope_long): the pairs are those of the samples from
 // `ibase` on, e_in = e[ibase - 1], *ychain = y[ibase - 1] on entry and y[ibase + 2 NT NBLK - 1] on return.
 // Returns this thread's maximum of |y| over the odd samples it stored (the accuracy guard's denominator when the low-pass is on).
-template <int NT, int NBLK, bool CHAINED = false>
+// INSIDE15: every block but the last lies entirely inside the row (n >= 15/16 of the samples the blocks cover): those blocks store
+// and take their maxima without a test per lane.
+template <int NT, int NBLK, bool CHAINED = false, bool INSIDE15 = false>
 __device__ __forceinline__ float lowpass_pairs_store_tab(const float (&er)[NBLK], const float (&ei)[NBLK], const LowpassConsts& K,
                                                         const f2_f4* __restrict__ lptab, unsigned char* smem,
                                                         double* __restrict__ y, int n, int tid, int ibase = 0, float e_in = 0.f,
@@ -236,12 +243,32 @@ __device__ __forceinline__ float lowpass_pairs_store_tab(const float (&er)[NBLK]
         const float y0 = fmaf(K.qf, fmaf(tc.y, ycar[jj], sprev), u0[jj]);
         const float y1 = fmaf(K.qf, y0, u1[jj]);
         const int i0 = ibase + 2 * (tid + NT * jj);
-        store_row_pair_buf(yb, n, i0, (double)y0, (double)y1);
         // every second output sample is enough for the maximum of a low-passed row (it only scales the guard's threshold);
         // block boundaries are wave-uniform: only the block that holds sample n - 1 masks per lane
-        const int lo = ibase + 2 * NT * jj;
-        if (lo + 2 * NT <= n) ymax = fmaxf(ymax, fabsf(y1));
-        else if (lo < n) ymax = fmaxf(ymax, i0 + 1 < n ? fabsf(y1) : fabsf(y0));
+        if constexpr (INSIDE15) {
+            if (jj < NBLK - 1) {
+                store_row_pair_inside(yb, i0, (double)y0, (double)y1);
+                ymax = fmaxf(ymax, fabsf(y1));
+            } else {
+                store_row_pair_buf(yb, n, i0, (double)y0, (double)y1);
+                ymax = fmaxf(ymax, i0 + 1 < n ? fabsf(y1) : (i0 < n ? fabsf(y0) : 0.f));
+            }
+        } else if constexpr (CHAINED) {
+            // (the long-row kernel is short of registers: per-lane tests cost it less than the uniform branches' live ranges)
+            store_row_pair_buf(yb, n, i0, (double)y0, (double)y1);
+            const int lo = ibase + 2 * NT * jj;
+            if (lo + 2 * NT <= n) ymax = fmaxf(ymax, fabsf(y1));
+            else if (lo < n) ymax = fmaxf(ymax, i0 + 1 < n ? fabsf(y1) : fabsf(y0));
+        } else {
+            const int lo = ibase + 2 * NT * jj;
+            if (lo + 2 * NT <= n) {                      // (wave-uniform: the whole block lies inside the row)
+                store_row_pair_inside(yb, i0, (double)y0, (double)y1);
+                ymax = fmaxf(ymax, fabsf(y1));
+            } else if (lo < n) {
+                store_row_pair_buf(yb, n, i0, (double)y0, (double)y1);
+                ymax = fmaxf(ymax, i0 + 1 < n ? fabsf(y1) : (i0 < n ? fabsf(y0) : 0.f));
+            }
+        }
     }
     return ymax;
 }
@@ -538,7 +565,7 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) {
         const int lo = 2 * NT * jj;
-        if (lo + 2 * NT <= n) {
+        if ((PADLAST && jj < NBLK - 1) || lo + 2 * NT <= n) {     // (PADLAST: every block but the last is inside the row)
             gin = fmaxf(gin, fmaxf(er[jj], ei[jj]));
         } else if (lo < n) {
             const int i0 = lo + 2 * tid;
@@ -556,11 +583,14 @@ __global__ __launch_bounds__((threads_for<float, LOG2H>()), (min_waves_for<float
     if (!P.lpf) {
         const __amdgpu_buffer_rsrc_t yb = row_buffer(y, n);
 #pragma unroll
-        for (int jj = 0; jj < NBLK; ++jj) store_row_pair_buf(yb, n, 2 * (tid + NT * jj), (double)er[jj], (double)ei[jj]);
+        for (int jj = 0; jj < NBLK; ++jj) {
+            if ((PADLAST && jj < NBLK - 1) || 2 * NT * (jj + 1) <= n) store_row_pair_inside(yb, 2 * (tid + NT * jj), (double)er[jj], (double)ei[jj]);
+            else if (2 * NT * jj < n) store_row_pair_buf(yb, n, 2 * (tid + NT * jj), (double)er[jj], (double)ei[jj]);
+        }
     } else {
         // the parity bar is written on the LOW-PASSED row (EnvelopeExtraction.py:57-66): its maximum, which a bursty row
         // keeps several times below the raw one, is what the residual is compared with
-        glp = wave_max63(lowpass_pairs_store_tab<NT, NBLK>(er, ei, P.lp, lptab, smem, y, n, tid));   // (contains barriers)
+        glp = wave_max63(lowpass_pairs_store_tab<NT, NBLK, false, PADLAST>(er, ei, P.lp, lptab, smem, y, n, tid));   // (contains barriers)
     }
     // No barrier for the verdict: every wave posts its maxima and then counts itself in; the LDS serves a wave's operations in
     // order, so the wave that counts in last sees everybody's maxima and decides for the row.
@@ -618,7 +648,7 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     constexpr int TWL = plan_tw_lds_count(LOG2Q);
     __shared__ __attribute__((aligned(16))) cpx<float> twl[TWL];
-    __shared__ unsigned guard[3];
+    __shared__ unsigned guard[4];
     __shared__ double ychain;
     cpx<float>* lds = reinterpret_cast<cpx<float>*>(smem);
 
@@ -643,7 +673,7 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
     const f2_f4* __restrict__ HUc = HUall + (size_t)c * P.tpitch;
 
     for (int i = tid; i < TWL; i += NT) twl[i] = tw[plan_tw_offset(LOG2Q, 1) + i];
-    if (tid < 3) guard[tid] = 0u;
+    if (tid < 4) guard[tid] = 0u;
     if (tid == 0) ychain = 0.0;
 
     const unsigned zstep = ((unsigned)NB0 * (unsigned)n) & (M - 1);
@@ -719,7 +749,8 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
                                                       F2_KSL_PARK_AUX);
 #endif
                 gin = fmaxf(gin, in ? e : 0.f);
-                if (4 * NT * (j + 1) > n) gout = fmaxf(gout, in ? 0.f : fabsf(a.re));   // (wave-uniform: blocks that hold padding)
+                // (rows of this class have n > 32768: blocks 0 .. 7 of 4096 samples never hold padding; wave-uniform test for the others)
+                if (j >= 8 && 4 * NT * (j + 1) > n) gout = fmaxf(gout, in ? 0.f : fabsf(a.re));
             }
         }
 #ifdef F2_STAMPS
@@ -774,12 +805,13 @@ __global__ __launch_bounds__(1024, 4) void k_spectral_envelope_long(
         else F2_SSTAMP(6);
 #endif
     }
-    if (P.lpf) {
-        glp = wave_max63(glp);
-        if ((tid & 63) == 63) atomicMax(&guard[2], __float_as_uint(glp));
-        __syncthreads();
+    // (verdict without a barrier, as in k_spectral_envelope: the wave that counts itself in last decides)
+    if (P.lpf) glp = wave_max63(glp);
+    if ((tid & 63) == 63) {
+        if (P.lpf) __hip_atomic_fetch_max(&guard[2], __float_as_uint(glp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__hip_atomic_fetch_add(&guard[3], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(NT / 64 - 1))
+            guard_decide(P, guard, b, c);
     }
-    if (tid == 0) guard_decide(P, guard, b, c);
 #ifdef F2_STAMPS
     F2_SSTAMP(7);
     if (tid == 0 && P.stamps)
