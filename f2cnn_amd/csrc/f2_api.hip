@@ -768,9 +768,11 @@ int f2_filterbank_envelope_fused(f2_ctx* ctx, const void* wave, int wave_dtype, 
     F2_TRY(f2_plan_handoff(ctx, offsets, B, C, fft_precision, d_gfb != nullptr, &handoff));
     double* k1_out = d_gfb ? d_gfb : d_env;
     F2_TRY(f2_launch_filterbank(ctx, d_wave, wave_dtype, (const int64_t*)ctx->offsets.ptr, offsets,
-                                (const double*)ctx->coefs.ptr, B, C, k1_out, &handoff, d_uflag));
+                                (const double*)ctx->coefs.ptr, B, C, k1_out, &handoff, d_uflag,
+                                d_uflag && ctx->spec_meta_host.size() >= (size_t)B ? ctx->spec_meta_host.data() : nullptr));
     F2_TRY(f2_launch_envelope(ctx, k1_out, (const int64_t*)ctx->offsets.ptr, offsets, B, C, lpf, cutoff_hz,
-                              fft_precision, d_env, &handoff, d_uflag));
+                              fft_precision, d_env, &handoff, d_uflag,
+                              d_uflag && ctx->spec_meta_host.size() >= (size_t)B ? ctx->spec_meta_host.data() : nullptr));
     if (staged) {
         F2_HIP(ctx, hipMemcpyAsync(env, d_env, bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (gfb_or_null) F2_HIP(ctx, hipMemcpyAsync(gfb_or_null, d_gfb, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -470,7 +470,7 @@ int f2_launch_envelope13_p3(f2_ctx* ctx, const f2_env_params& P, int precision, 
 #else
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
                        int B, int C, int lpf, double cutoff_hz, int precision, double* d_env, const f2_handoff* handoff,
-                       const int* d_uflag) {
+                       const int* d_uflag, const int* h_flag0) {
     const bool f32_in = handoff && handoff->f32;
     F2_CHECK(ctx, !f32_in || precision == F2_FFT_F32, F2_ERR_INVALID, "float32 hand-off needs the float FFT");
     EnvParams P;
@@ -538,6 +538,20 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
             F2_TRY(f2_launch_envelope_split(ctx, d_gfb, d_env, d_offsets, split_groups[log2h].data(),
                                             (int)split_groups[log2h].size(), log2h, C, P.lpf, P.b0, P.a1,
                                             f32_in ? handoff->d_x32 : nullptr, f32_in ? handoff->d_x32_off : nullptr, d_uflag));
+    // Utterances of the spectral kernel's length classes that the HOST kept off that route (flag 1 from the start: too little
+    // padding for its accuracy guard) are known here: they go first in their group and get one workgroup per row like any
+    // envelope launch; the launch that walks the flags with 1 / 16 of the workgroups serves the rest, which only the guard can
+    // send back. (All of them behind that launch took 0.9 + 0.5 ms per 2500-utterance launch of the ragged corpus: sixteen rows
+    // one after the other on the few workgroups that own an active utterance.)
+    std::vector<int> nactive(32, 0);
+    bool reordered = false;
+    if (d_uflag && h_flag0 && precision == F2_FFT_F32)
+        for (int l = F2_SPECTRAL_MIN_LOG2H; l <= 14; ++l) {
+            auto& g = groups[l];
+            const auto mid = std::stable_partition(g.begin(), g.end(), [&](int b) { return h_flag0[b] != 0; });
+            nactive[l] = (int)(mid - g.begin());
+            reordered = reordered || (nactive[l] > 0 && nactive[l] < (int)g.size());
+        }
     size_t list_elems = 0;
     int ngroups = 0;
     for (auto& g : groups)
@@ -545,7 +559,7 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
             ++ngroups;
             list_elems += g.size();
         }
-    const bool identity = ngroups == 1 && (int)list_elems == B && n_large == 0;
+    const bool identity = ngroups == 1 && (int)list_elems == B && n_large == 0 && !reordered;
     int* d_lists = nullptr;
     if (!identity && ngroups > 0) {
         std::vector<int> flat;
@@ -559,27 +573,40 @@ int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offset
     for (int log2h = 0; log2h < 32; ++log2h) {
         const auto& g = groups[log2h];
         if (g.empty()) continue;
-        P.ulist = identity ? nullptr : d_lists + pos;
+        const int* list = identity ? nullptr : d_lists + pos;
         pos += g.size();
         const int nthreads = (log2h == 14 && precision == F2_FFT_F32) ? 1024
                              : (log2h == 13 && precision == F2_FFT_F32) ? F2_THREADS13 : log2h >= 13 ? 512 : 256;   // threads_for<F, LOG2H>()
-        const dim3 grid((unsigned)(g.size() * (size_t)C)), block(nthreads);
+        // one workgroup per row for the utterances ulist[0 .. count)
+        auto launch_rows = [&](const int* ulist, size_t count) -> int {
+            P.ulist = ulist;
+            const dim3 grid((unsigned)(count * (size_t)C)), block(nthreads);
+            if (log2h == 13 && (!P.lpf || precision == F2_FFT_F64) && !ctx->opt_env_plan4) {
+                // the 1 s row without the float low-pass: three-pass plan (f2_envelope_p3.hip)
+                F2_TRY(f2_launch_envelope13_p3(ctx, P, precision, (unsigned)(count * (size_t)C)));
+            } else if (precision == F2_FFT_F32) {
+                F2_TRY(ensure_twiddles<float>(ctx, log2h, ctx->tw[0][log2h]));
+                const EnvKernel<float> kern = kernel_for<float, MAX_LOG2H_F32>(log2h);
+                hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, P, (const cpx<float>*)ctx->tw[0][log2h].ptr);
+            } else {
+                F2_TRY(ensure_twiddles<double>(ctx, log2h, ctx->tw[1][log2h]));
+                const EnvKernel<double> kern = kernel_for<double, MAX_LOG2H_F64>(log2h);
+                hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, P, (const cpx<double>*)ctx->tw[1][log2h].ptr);
+            }
+            return F2_OK;
+        };
         F2_TRY(f2_prof_begin(ctx, F2_K_ENVELOPE));
         if (precision == F2_FFT_F32 && P.uflag && log2h >= F2_SPECTRAL_MIN_LOG2H && log2h <= 14) {
-            // a length class the spectral kernel serves: its utterances only come here when the guard flags them (or the
-            // host routed them here: too little padding) - walked by far fewer workgroups (f2_envelope_flagged.hip)
-            F2_TRY(f2_launch_envelope_flagged(ctx, P, log2h, (unsigned)g.size()));
-        } else if (log2h == 13 && (!P.lpf || precision == F2_FFT_F64) && !ctx->opt_env_plan4) {
-            // the 1 s row without the float low-pass: three-pass plan (f2_envelope_p3.hip)
-            F2_TRY(f2_launch_envelope13_p3(ctx, P, precision, (unsigned)(g.size() * (size_t)C)));
-        } else if (precision == F2_FFT_F32) {
-            F2_TRY(ensure_twiddles<float>(ctx, log2h, ctx->tw[0][log2h]));
-            const EnvKernel<float> kern = kernel_for<float, MAX_LOG2H_F32>(log2h);
-            hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, P, (const cpx<float>*)ctx->tw[0][log2h].ptr);
+            // a length class the spectral kernel serves: the utterances the host routed here first, one workgroup per row;
+            // the others only come here when the guard flags them - walked by far fewer workgroups (f2_envelope_flagged.hip)
+            const size_t na = (size_t)nactive[log2h];
+            if (na > 0) F2_TRY(launch_rows(list, na));
+            if (na < g.size()) {
+                P.ulist = list ? list + na : nullptr;
+                F2_TRY(f2_launch_envelope_flagged(ctx, P, log2h, (unsigned)(g.size() - na)));
+            }
         } else {
-            F2_TRY(ensure_twiddles<double>(ctx, log2h, ctx->tw[1][log2h]));
-            const EnvKernel<double> kern = kernel_for<double, MAX_LOG2H_F64>(log2h);
-            hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, P, (const cpx<double>*)ctx->tw[1][log2h].ptr);
+            F2_TRY(launch_rows(list, g.size()));
         }
         F2_HIP(ctx, hipGetLastError());
         F2_TRY(f2_prof_end(ctx, F2_K_ENVELOPE));

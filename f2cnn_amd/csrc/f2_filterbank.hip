@@ -473,7 +473,7 @@ int split_segments(int units, int64_t nmax, bool f32_out, int forced) {   // for
 
 int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,
                          const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb,
-                         const f2_handoff* handoff, const int* d_uflag) {
+                         const f2_handoff* handoff, const int* d_uflag, const int* h_flag0) {
     const bool f32_out = handoff && handoff->f32;
     float* alt = f32_out ? handoff->d_x32 : nullptr;
     const int64_t* alt_off = f32_out ? handoff->d_x32_off : nullptr;
@@ -486,7 +486,20 @@ int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const 
     if (a2zero) {
         int64_t nmax = 0;
         for (int b = 0; b < B; ++b) nmax = std::max(nmax, h_offsets[b + 1] - h_offsets[b]);
-        const int K = split_segments(units, nmax, f32_out, ctx->opt_k1_split);
+        // Utterances the spectral kernel serves are skipped (flag 0) unless its accuracy guard hands them back, which is rare:
+        // what this launch has to WORK on is known on the host - the utterances whose flag starts at 1 - and when those are a
+        // handful of a large batch (the 1-2 % of a ragged corpus whose rows have too little padding for that route), a wave per
+        // unit would walk a whole utterance serially while the chip idles (2.3 ms per 2500-utterance launch of the ragged
+        // corpus for 1 % of its samples): the time-split path is chosen by the ACTIVE units then, with few enough segments
+        // that the waves of skipped utterances (which return at once) stay cheap to launch.
+        int active_units = units;
+        if (d_uflag && h_flag0) {
+            int na = 0;
+            for (int b = 0; b < B; ++b) na += h_flag0[b] != 0;
+            active_units = na * groups;
+        }
+        int K = split_segments(active_units > 0 ? active_units : units, nmax, f32_out, ctx->opt_k1_split);
+        if (active_units != units && ctx->opt_k1_split < 2) K = (int)std::min<int64_t>(K, std::max<int64_t>(1, 65536 / std::max(units, 1)));
         if (K > 1) {
             sp.L = (int)(((nmax + K - 1) / K + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN);
             sp.K = (int)((nmax + sp.L - 1) / sp.L);

@@ -235,12 +235,14 @@ struct f2_handoff {
 int f2_plan_handoff(f2_ctx* ctx, const int64_t* h_offsets, int B, int C, int precision, bool want_gfb, f2_handoff* plan);
 // d_uflag (device, B ints) != NULL: only utterances whose flag is non-zero are processed (the rest were served by the
 // spectral kernel); the flags may be written by earlier launches on the stream.
+// h_flag0 (host, B ints, with d_uflag): the flags as they are before the spectral kernel runs - the utterances this launch
+// certainly has to process (its launch shape is chosen for them; any utterance may still be handed back by the guard).
 int f2_launch_filterbank(f2_ctx* ctx, const void* d_wave, int wave_dtype, const int64_t* d_offsets,
                          const int64_t* h_offsets, const double* d_coefs, int B, int C, double* d_gfb,
-                         const f2_handoff* handoff = nullptr, const int* d_uflag = nullptr);
+                         const f2_handoff* handoff = nullptr, const int* d_uflag = nullptr, const int* h_flag0 = nullptr);
 int f2_launch_envelope(f2_ctx* ctx, const double* d_gfb, const int64_t* d_offsets, const int64_t* h_offsets,
                        int B, int C, int lpf, double cutoff_hz, int precision, double* d_env,
-                       const f2_handoff* handoff = nullptr, const int* d_uflag = nullptr);
+                       const f2_handoff* handoff = nullptr, const int* d_uflag = nullptr, const int* h_flag0 = nullptr);
 // Spectral filterbank + envelope (f2_spectral.hip): which utterances / coefficient tables it serves, and the launch for
 // the utterances d_ulist[0..nutt) (all of length class log2h). Rows that fail its accuracy guard set d_uflag[b].
 bool f2_spectral_supports_len(int64_t n, int min_pad);
