@@ -248,7 +248,10 @@ __global__ __launch_bounds__((threads_for<F, LOG2H>()), (min_waves_for<F, LOG2H>
 #pragma unroll
                 for (int j = 0; j < R0; ++j) {
                     const cpx<F> e = v[i * R0 + brev<R0>(j)];
-                    store_row_pair(y, n, 2 * (bf + j * NB0), (double)e.re, (double)e.im);
+                    // (the points of a butterfly index j are NB0 apart: block j of 2 NB0 samples; inside the row - a wave-uniform
+                    // test - it stores without a test per lane)
+                    if (FULL0 && 2 * NB0 * (j + 1) <= n) store_pair(y + 2 * (bf + j * NB0), (double)e.re, (double)e.im);
+                    else store_row_pair(y, n, 2 * (bf + j * NB0), (double)e.re, (double)e.im);
                 }
             }
         }

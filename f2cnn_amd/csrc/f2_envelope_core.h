@@ -17,7 +17,19 @@ __device__ __forceinline__ cpx<F> operator+(cpx<F> a, cpx<F> b) { return {a.re +
 template <typename F>
 __device__ __forceinline__ cpx<F> operator-(cpx<F> a, cpx<F> b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ float fsqrt(float v) { return __builtin_amdgcn_sqrtf(v); }   // v_sqrt_f32, 1 ulp
-__device__ __forceinline__ double fsqrt(double v) { return sqrt(v); }
+// float64 magnitude: v_rsq_f64 (~2^-26), one Goldschmidt step (2^-52) and the residual correction - within an ulp or two of
+// sqrt for every normal argument (the envelope is held to 1e-10; the correctly rounded library sqrt adds a second step, argument
+// scaling and class tests: ~25 instructions where this has 8, a sixth of the float64 arithmetic of the float64 envelope kernel)
+__device__ __forceinline__ double fsqrt(double s) {
+    const double r = __builtin_amdgcn_rsq(s);
+    double g = s * r, h = 0.5 * r;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, s);
+    g = fma(d, h, g);
+    return s > 0.0 ? g : 0.0;      // (s = 0: rsq = inf, 0 x inf)
+}
 template <typename F>
 __device__ __forceinline__ cpx<F> cmul(cpx<F> a, cpx<F> w) {
     return {a.re * w.re - a.im * w.im, a.re * w.im + a.im * w.re};
@@ -288,7 +300,9 @@ __device__ __forceinline__ double lowpass_pairs_store(const F (&er)[NBLK], const
         const F y0 = qf * (gtf * (F)ycarry + sprev) + u0[jj];
         const F y1 = qf * y0 + u1[jj];
         const int i0 = 2 * (tid + NT * jj);
-        store_row_pair(y, n, i0, (double)y0, (double)y1);
+        // (a block that lies inside the row - a wave-uniform test - stores without a test per lane)
+        if (2 * NT * (jj + 1) <= n) store_pair(y + i0, (double)y0, (double)y1);
+        else if (2 * NT * jj < n) store_row_pair(y, n, i0, (double)y0, (double)y1);
         ycarry = fma(gblk, ycarry, btot[jj]);
     }
     return ycarry;
