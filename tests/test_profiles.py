@@ -34,3 +34,14 @@ def test_default_line_keeps_the_contract_fields():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     t = json.load(open(newest("r*_traffic_cfg3.json")))
     assert r["traffic"] is None or t[r["kernel"]]["hbm_bytes_per_launch"] == r["traffic"]
+
+
+def test_the_committed_traffic_counters_belong_to_the_kernels_in_the_tree():
+    """bench.py quotes `roofline.traffic` (HBM bytes per launch from the rocprofv3 --pmc passes) only while the hash of
+    f2cnn_amd/csrc/* equals the one stamped into the newest profiles/r*_traffic_cfg3.json - a kernel edit after the last profile
+    round silently turns the field into null. Re-run tools/profile_round.sh and copy its traffic file when this fails."""
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(newest("r*_traffic_cfg3.json")))
+    assert t["lib_source_hash"] == bench.lib_source_hash()
+    assert bench.measured_traffic("cfg3", 1000, 128, 16000, "f32")["k_spectral_envelope"] >= 8 * 128 * 16000 * 1000
