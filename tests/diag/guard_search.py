@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--npz", default=None, help="per-utterance arrays for offline analysis")
     ap.add_argument("--min-pad", type=int, default=-1, help="padding samples a row needs for the route (-1: the library's rule, "
                     "256 for this bank; 64 shows what the rule is for)")
+    ap.add_argument("--low-freq", type=float, default=100.0, help="lowest centre frequency of the bank (the reference's config: 100)")
     ap.add_argument("--rows", action="store_true", help="... and the per-row arrays of the 128-channel configurations")
     args = ap.parse_args()
     ctx = _lib.Context(0)
@@ -89,14 +90,18 @@ def main():
         print(s, flush=True)
         lines.append(s)
 
-    say(f"# guard search: {args.per_class} utterances per length class, spectral_tol = {tol:g}, spectral_min_pad = {args.min_pad}, families = {', '.join(speechlike.FAMILIES)}")
-    coefs = {C: filters.make_erb_filters(16000, filters.centre_freqs(16000, C, 100)) for C in CHANNELS}
+    say(f"# guard search: {args.per_class} utterances per length class, spectral_tol = {tol:g}, spectral_min_pad = {args.min_pad}, low_freq = {args.low_freq:g}, families = {', '.join(speechlike.FAMILIES)}")
+    coefs = {C: filters.make_erb_filters(16000, filters.centre_freqs(16000, C, args.low_freq)) for C in CHANNELS}
     dump = {}
     overall_worst_unflagged = 0.0
     for log2m in [int(x) for x in args.classes.split(",")]:
         t_class = time.time()
         rng = np.random.default_rng(log2m)
-        pad = 256 if args.min_pad < 0 else args.min_pad
+        if args.min_pad < 0:      # the library's rule: 1.1 x the ringing peak time of the slowest channel, rounded up to 32
+            a2 = coefs[CHANNELS[0]][:, 8] / coefs[CHANNELS[0]][:, 6]
+            pad = (int(np.ceil(1.1 * (3.0 / (-0.5 * np.log(a2))).max())) + 31) // 32 * 32
+        else:
+            pad = args.min_pad
         nmax = (1 << log2m) - pad
         Bb = max(8, min(250, (1 << 31) // (8 * 128 * nmax)))
         nbatch = (args.per_class + Bb - 1) // Bb
