@@ -138,17 +138,34 @@ __device__ __forceinline__ void filterbank_unit(const WaveT* __restrict__ wave, 
             wave_sync();
             double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const double* e = sp.states + ((size_t)unit * K) * 8 * 64 + lane;
-            for (int j = 0; j < seg; ++j, e += 8 * 64) {
-                double Sn[8];
+            // The end states E_j of the segments before this one, four steps ahead of the chain that consumes them: read one
+            // step at a time, every step waited out a round trip to L2 for its eight words (31 steps: ~40 of the 61 us a single
+            // 1 s utterance spent in this kernel).
+            constexpr int AHEAD = 4;
+            double eb[AHEAD][8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    double acc = e[r * 64];
+            for (int a = 0; a < AHEAD; ++a)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc = fma(mshw[r * 8 + q][lane], S[q], acc);
-                    Sn[r] = acc;
+                for (int r = 0; r < 8; ++r) eb[a][r] = e[(size_t)min(a, K - 1) * (8 * 64) + r * 64];
+            for (int j0 = 0; j0 < seg; j0 += AHEAD) {
+#pragma unroll
+                for (int a = 0; a < AHEAD; ++a) {
+                    if (j0 + a < seg) {                       // (wave-uniform)
+                        double Sn[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            double acc = eb[a][r];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) acc = fma(mshw[r * 8 + q][lane], S[q], acc);
+                            Sn[r] = acc;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) S[r] = Sn[r];
+                        const int jn = min(j0 + a + AHEAD, K - 1);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) eb[a][r] = e[(size_t)jn * (8 * 64) + r * 64];
+                    }
                 }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) S[r] = Sn[r];
             }
             z10 = S[0], z11 = S[1], z20 = S[2], z21 = S[3], z30 = S[4], z31 = S[5], z40 = S[6], z41 = S[7];
         }
@@ -464,8 +481,13 @@ int split_segments(int units, int64_t nmax, bool f32_out, int forced) {   // for
     if (forced == 0 || nmax < 2 * SEG_ALIGN) return 1;
     // (measured, tools/k1_small_batch.py: with the float32 hand-off 192 units gain 1.7x, 384 units break even, 512 lose
     // 15 %; with float64 output, which is bound by its stores, 512 units lose 25 %)
-    int K = forced >= 2 ? forced : (units <= (f32_out ? 320 : 256) ? std::min(32, 2048 / std::max(units, 1)) : 1);
-    K = (int)std::min<int64_t>(K, (nmax + 8 * SEG_ALIGN - 1) / (8 * SEG_ALIGN));   // at least 256 samples per segment
+    // (one or two utterances - `cnn eval` of a file, BASELINE's cfg1: 64 segments. The kernel pair costs ~2 L x 47 ns + 0.2 us
+    // x K + 8 us, flat between K = 64 and 100 for 1 s: 56 -> 45 us; from 16 units on 32 segments are the better choice:
+    // tools/k1_split_sweep.py, profiles/r05_k1_split_sweep.txt)
+    const int kmax = units <= 4 ? 64 : 32;
+    int K = forced >= 2 ? forced : (units <= (f32_out ? 320 : 256) ? std::min(kmax, 2048 / std::max(units, 1)) : 1);
+    const int min_seg = units <= 4 ? 4 * SEG_ALIGN : 8 * SEG_ALIGN;                  // at least 128 / 256 samples per segment
+    K = (int)std::min<int64_t>(K, (nmax + min_seg - 1) / min_seg);
     return std::max(K, 1);
 }
 
