@@ -1218,6 +1218,9 @@ static int cnn_ws_selfcheck(f2_ctx* ctx, f2_cnn* cnn) {
     };
     cnn->ws_check_diff = maxdiff(1, 0);
     cnn->ws_dense_check_diff = maxdiff(2, 1);
+#ifdef F2_WS_KEEP_ANYWAY    // timing knock-outs (tools/build_variant.sh) compute wrong results on purpose
+    return F2_OK;
+#endif
     if (!(cnn->ws_check_diff <= TOL)) {
         cnn->ws_ok = cnn->ws_dense_ok = false;
         fprintf(stderr, "[libf2cnn_hip] weight-stationary CNN kernels disagree with the per-tile kernels by %.3g on the "

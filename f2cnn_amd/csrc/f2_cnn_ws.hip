@@ -31,8 +31,9 @@
 //                 accumulator rows = output channels as above); waves 4-7: the two K halves of tile t - 1 meet (first half: sum,
 //                 pool, bias, store), then conv4 (output tile nt, K half) of tile t from patch B.
 //
-//   k_dense1_ws   96 windows x 6 output tiles per 6-wave workgroup (two per CU), weights streamed two 16-byte loads per lane
-//                 and K step into a ring, activations split on their way into LDS; every load of the K loop waited for by hand.
+//   k_dense1_ws   2 x 96 windows x 6 output tiles per 12-wave workgroup (one per CU, three waves on every SIMD), weights streamed
+//                 two 16-byte loads per lane and K step into a ring, activations split on their way into LDS and fetched a K step
+//                 ahead of their MFMAs; every load of the K loop waited for by hand.
 //
 // Layout of an MFMA operand (tools/ubench/mfma_bf16_layout.hip, mfma_f16_split.hip: the two forms share it): lane (i, h) supplies k = 8 h .. 8 h + 7 of row / column i;
 // accumulator register q of lane (i, h) is row (q & 3) + 8 (q >> 2) + 4 h, column i.
@@ -92,7 +93,7 @@ __device__ __forceinline__ void tile_split(unsigned t, tile_div td, unsigned& q,
 #define WS_STAMP_ARG , unsigned long long* stamps
 #define WS_STAMP(it, slot)                                                                                              \
     do {                                                                                                                \
-        if (stamps && blockIdx.x < 8 && (it) >= 8 && (it) < 40 && lane == 0) {                                          \
+        if (stamps && blockIdx.x < 8 && wave < 8 && (it) >= 8 && (it) < 40 && lane == 0) {                                          \
             unsigned long long* sp_ = stamps + ((((size_t)blockIdx.x * 8 + wave) * 32 + ((it) - 8)) * 8);               \
             sp_[slot] = __builtin_amdgcn_s_memtime();                                                                   \
             if ((slot) == 0) sp_[7] = __builtin_amdgcn_s_memrealtime();                                                 \
@@ -714,22 +715,42 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
 // global load of the K loop is issued and waited for by hand (two K steps ahead for the weights, a chunk ahead for the
 // activations), and the activations' hi / lo chunks sit XOR-swizzled in LDS so that ds_read_b128 of 32 consecutive rows is
 // conflict-free (chunk c of row r at r * 128 + ((c ^ ((r >> 1) & 7)) << 4): a 16-lane group of the read covers eight even and eight
-// odd rows, whose halves of the 256-byte bank window are fixed by the row's parity). 6 waves = 6 output tiles per workgroup, two workgroups
-// per CU. (conv4 leaving its outputs already split - two 2-byte stores or one packed dword per value - was measured too: it
-// takes 18 us out of this kernel's staging and puts them into k_conv34_ws's combine, which runs beside matrix loops.)
+// odd rows, whose halves of the 256-byte bank window are fixed by the row's parity). (conv4 leaving its outputs already split - two
+// 2-byte stores or one packed dword per value - was measured too: it takes 18 us out of this kernel's staging and puts them into
+// k_conv34_ws's combine, which runs beside matrix loops.)
+// Workgroup shape (round 5, profiles/r05_dense1_*.txt): a workgroup's waves go to SIMD (wave % 4), every workgroup starting at SIMD
+// 0, so two resident 6-wave workgroups loaded the SIMDs 4, 4, 2, 2 - with every other cost knocked out the kernel stood at the
+// matrix time of the 4-wave SIMDs (98 of 122 us per 14 240 windows). Now 12 waves = 2 row halves x 6 output tiles: three waves
+// per SIMD, one workgroup per CU, 164 registers. What is left (113 us against 58 us of matrix time): the activation fragments -
+// 2 KB of LDS reads per 3 MT MFMAs and wave, 22 us with everything else knocked out - and the launch's fixed costs.
 constexpr int D1W_WAVES = 6, D1W_KC = 64, D1W_TILES = 17, D1W_NPAD = D1W_TILES * 32, D1W_N = 516;
+constexpr int D1W_GROUPS = (D1W_TILES + D1W_WAVES - 1) / D1W_WAVES;
+#ifndef F2_D1W_HALVES
+#define F2_D1W_HALVES 2
+#endif
+constexpr int D1W_HALVES = F2_D1W_HALVES;      // row halves of a workgroup: 6 x 2 = 12 waves, three on every SIMD
+constexpr int D1W_THREADS = D1W_WAVES * D1W_HALVES * 64;
 template <int MT>
-__global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __restrict__ a, const h16x8* __restrict__ ws,
+__global__ __launch_bounds__(D1W_THREADS, 3) void k_dense1_ws(const float* __restrict__ a, const h16x8* __restrict__ ws,
                                                                  const float* __restrict__ bias, float* __restrict__ out, int K,
-                                                                 int64_t n, f2_split_scales S) {
-    constexpr int ROWS = 32 * MT, PIECE = ROWS * 128, BUF = 2 * PIECE;
-    static_assert(2 * BUF <= 80 * 1024 && 2 * BUF - 1 + 0 < 65536, "two workgroups per CU; immediate ds offsets");
+                                                                 int64_t n, f2_split_scales S WS_STAMP_ARG) {
+    constexpr int ROWS = 32 * MT * D1W_HALVES, PIECE = ROWS * 128, BUF = 2 * PIECE;
+    static_assert(2 * BUF <= 160 * 1024 && PIECE + 32 * MT * 128 < 65536, "LDS of a CU; immediate ds offsets from a half's base");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int64_t w0 = (int64_t)blockIdx.x * ROWS;
+    // Workgroup -> (row block rb, tile group ty). The D1W_GROUPS workgroups that share a row block's activations sit on the same
+    // XCD (workgroup L runs on XCD L % 8) and next to each other in dispatch order, so that the block's K chunks come from HBM
+    // once and from that XCD's L2 for the others; with gridDim = (row blocks, groups) they were a whole grid row apart and
+    // every group re-read all activations from HBM (3 x 875 MB per 113 920 windows: the kernel's bound).
+    const unsigned gq = blockIdx.x / (8 * D1W_GROUPS), gr = blockIdx.x - gq * (8 * D1W_GROUPS);
+    const int ty = gr >> 3;
+    const int64_t rb = (int64_t)gq * 8 + (gr & 7);
+    const int64_t w0 = rb * ROWS;
+    if (w0 >= n) return;                                             // (workgroup-uniform, ahead of every barrier)
     const int nchunks = K / D1W_KC, nsteps = nchunks * 4;
-    const int nt = blockIdx.y * D1W_WAVES + wave;
+    const int hf = wave / D1W_WAVES;                                 // row half: rows 32 MT hf .. of the workgroup's
+    const int nt = ty * D1W_WAVES + (wave - hf * D1W_WAVES);
     const bool live = nt < D1W_TILES;
     const int ntc = live ? nt : D1W_TILES - 1;                       // (idle waves load a valid tile and discard it)
     const h16x8* wh = ws + (int64_t)h * D1W_NPAD + ntc * 32 + i;    // w[piece][chunk][ks][h][n (544)][8]
@@ -739,16 +760,16 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
     // 16-byte LDS stores (hi and lo chunk) at position c ^ ((row >> 1) & 7) of the row in either piece; rows
     // past n read row n - 1 (their results are not stored). Through registers rather than by LDS-DMA: vmcnt counts in order, so a
     // wait for a weight fragment also waits for everything issued before it - either way two K steps after its issue.
-    constexpr int NPAIR = ROWS * 8, PERT = (NPAIR + D1W_WAVES * 64 - 1) / (D1W_WAVES * 64);
+    constexpr int NPAIR = ROWS * 8, PERT = (NPAIR + D1W_THREADS - 1) / D1W_THREADS;
     unsigned srcoff[PERT];
     int dstoff[PERT];
 #pragma unroll
     for (int m = 0; m < PERT; ++m) {
-        const int sl = min((int)threadIdx.x + D1W_WAVES * 64 * m, NPAIR - 1);
+        const int sl = min((int)threadIdx.x + D1W_THREADS * m, NPAIR - 1);
         const int row = sl >> 3, c = sl & 7;
         const int64_t wr = w0 + row < n ? w0 + row : n - 1;
         srcoff[m] = (unsigned)(wr * (int64_t)K + c * 8) * 4u;                    // bytes (n x K dwords < 4 GB: f2_launch_dense1_ws checks)
-        dstoff[m] = (int)threadIdx.x + D1W_WAVES * 64 * m < NPAIR ? row * 128 + ((c ^ ((row >> 1) & 7)) << 4) : -1;
+        dstoff[m] = (int)threadIdx.x + D1W_THREADS * m < NPAIR ? row * 128 + ((c ^ ((row >> 1) & 7)) << 4) : -1;
     }
     // Every global load of the K loop is issued through inline asm and waited for by hand: left to the compiler, the waits at the
     // head of the loop come out as vmcnt(0) - the fragment requested a moment ago included (a full L2 latency per chunk).
@@ -756,6 +777,9 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
     u32x4 ar[2 * PERT];
     auto gload = [](u32x4& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory"); };
     auto load_a = [&](int kc) {
+#ifdef F2_D1W_KO_A      // timing knock-out: the activations of chunk 0 again (cache hits)
+        kc = 0;
+#endif
 #pragma unroll
         for (int m = 0; m < PERT; ++m) {
             const unsigned char* p = reinterpret_cast<const unsigned char*>(a) + srcoff[m] + kc * (D1W_KC * 4);
@@ -789,27 +813,42 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
     // weight fragments: a ring of four K steps (slot = ks, compile-time)
     u32x4 bh[4], bl[4];
     auto load_b = [&](int step, int slot) {
+#ifdef F2_D1W_KO_W      // timing knock-out (tools/build_variant.sh): every step re-reads the fragment of step `slot` (L1 hits)
+        step = slot;
+#endif
         gload(bh[slot], wh + (int64_t)step * 2 * D1W_NPAD);
         gload(bl[slot], wl + (int64_t)step * 2 * D1W_NPAD);
     };
     // (the fragment is an operand of the wait, so that its MFMAs cannot be scheduled ahead of it)
 #define D1W_WAIT(N, slot) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bh[slot]), "+v"(bl[slot])::"memory")
-    auto step_mfmas = [&](const unsigned char* pa, int ks) {
-        // activations one M tile ahead of the MFMAs that use them
-        const h16x8 wb_h = __builtin_bit_cast(h16x8, bh[ks]), wb_l = __builtin_bit_cast(h16x8, bl[ks]);
-        h16x8 ah[2], al[2];
-        ah[0] = *reinterpret_cast<const h16x8*>(pa + aoff[ks]);
-        al[0] = *reinterpret_cast<const h16x8*>(pa + aoff[ks] + PIECE);
+    // Activation fragments of a K step: MT x (hi, lo) ds_read_b128, requested a whole step ahead of the MFMAs that use them
+    // (two register sets). Left to the compiler they are read two at a time right in front of their MFMAs - three exposed LDS
+    // latencies per step and wave.
+    h16x8 fah[2][MT], fal[2][MT];
+    auto fetch = [&](const unsigned char* pa, int ks, int set) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            if (t + 1 < MT) {
-                ah[(t + 1) & 1] = *reinterpret_cast<const h16x8*>(pa + aoff[ks] + (t + 1) * 4096);
-                al[(t + 1) & 1] = *reinterpret_cast<const h16x8*>(pa + aoff[ks] + (t + 1) * 4096 + PIECE);
-            }
-            acc[t] = MFMA16(al[t & 1], wb_h, acc[t]);
-            acc[t] = MFMA16(ah[t & 1], wb_l, acc[t]);
-            acc[t] = MFMA16(ah[t & 1], wb_h, acc[t]);
+#ifdef F2_D1W_KO_LDSR   // timing knock-out: no LDS reads in the loop
+            fal[set][t] = __builtin_bit_cast(h16x8, bh[t]);
+            fah[set][t] = __builtin_bit_cast(h16x8, bl[t]);
+#else
+            fal[set][t] = *reinterpret_cast<const h16x8*>(pa + aoff[ks] + t * 4096 + PIECE);
+            fah[set][t] = *reinterpret_cast<const h16x8*>(pa + aoff[ks] + t * 4096);
+#endif
         }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // The three products of an accumulator depend on each other, so the M tiles take turns: product p of tiles 0 .. MT - 1,
+    // then product p + 1 (per accumulator the order of summation is lo x hi, hi x lo, hi x hi as everywhere).
+    auto step_mfmas = [&](int ks, int set) {
+        const h16x8 wb_h = __builtin_bit_cast(h16x8, bh[ks]), wb_l = __builtin_bit_cast(h16x8, bl[ks]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = MFMA16(fal[set][t], wb_h, acc[t]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = MFMA16(fah[set][t], wb_l, acc[t]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = MFMA16(fah[set][t], wb_h, acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
     };
     // Fragments are requested THREE steps ahead (the ring's fourth slot is the one the previous step has just consumed). Issue
     // order of a chunk: activations of chunk kc + 1 (2 PERT loads), then per step one fragment pair; a wait for the fragment
@@ -833,37 +872,54 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
     } while (0)
     int kc = 0;
     for (; kc + 1 < nchunks; ++kc) {
+        const unsigned char* pa = lds + (kc & 1) * BUF + hf * (32 * MT * 128);
+        WS_STAMP(kc, 0);
+        fetch(pa, 0, 0);
         load_a(kc + 1);
-        const unsigned char* pa = lds + (kc & 1) * BUF;
         load_b(kc * 4 + 3, 3);
+        fetch(pa, 1, 1);
         D1W_WAIT_NA(0);
-        step_mfmas(pa, 0);
+        WS_STAMP(kc, 1);
+        step_mfmas(0, 0);
         load_b(kc * 4 + 4, 0);
+        fetch(pa, 2, 0);
         D1W_WAIT_NA(1);
-        step_mfmas(pa, 1);
+        step_mfmas(1, 1);
         load_b(kc * 4 + 5, 1);
+        fetch(pa, 3, 1);
         D1W_WAIT_NA(2);
-        step_mfmas(pa, 2);
+        step_mfmas(2, 0);
         load_b(kc * 4 + 6, 2);
         D1W_WAIT(6, 3);
 #pragma unroll
         for (int m = 0; m < 2 * PERT; ++m) asm volatile("" : "+v"(ar[m]));
-        step_mfmas(pa, 3);
+        step_mfmas(3, 1);
+        WS_STAMP(kc, 2);
+#ifndef F2_D1W_KO_STORE  // timing knock-out: no split, no LDS stores
         store_a((kc + 1) & 1);                                       // (that buffer was read in chunk kc - 1: behind that chunk's barrier)
+#endif
+        WS_STAMP(kc, 4);
+#ifndef F2_D1W_KO_BAR    // timing knock-out: no barrier
         __syncthreads();
+#endif
+        WS_STAMP(kc, 3);
     }
     {
         // last chunk: fragments 0 - 2 are in flight, 3 still to request
-        const unsigned char* pa = lds + (kc & 1) * BUF;
+        const unsigned char* pa = lds + (kc & 1) * BUF + hf * (32 * MT * 128);
+        fetch(pa, 0, 0);
         load_b(kc * 4 + 3, 3);
+        fetch(pa, 1, 1);
         D1W_WAIT(6, 0);
-        step_mfmas(pa, 0);
+        step_mfmas(0, 0);
+        fetch(pa, 2, 0);
         D1W_WAIT(4, 1);
-        step_mfmas(pa, 1);
+        step_mfmas(1, 1);
+        fetch(pa, 3, 1);
         D1W_WAIT(2, 2);
-        step_mfmas(pa, 2);
+        step_mfmas(2, 0);
         D1W_WAIT(0, 3);
-        step_mfmas(pa, 3);
+        step_mfmas(3, 1);
     }
 #undef D1W_WAIT_NA
 #undef D1W_WAIT
@@ -875,7 +931,7 @@ __global__ __launch_bounds__(D1W_WAVES * 64, 3) void k_dense1_ws(const float* __
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int64_t wr = w0 + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int64_t wr = w0 + hf * (32 * MT) + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (wr < n) out[wr * D1W_N + col] = relu(fmaf(acc[t][q], S.cd, b));
             }
     }
@@ -981,11 +1037,24 @@ int f2_launch_dense1_ws(f2_ctx* ctx, const f2_cnn* cnn, const float* a4, int64_t
 #define F2_D1W_MT 3
 #endif
     constexpr int MT = F2_D1W_MT;
-    constexpr int LDSB = 2 * 2 * 32 * MT * 128;
+#ifdef F2_D1W_ONE_WG     // timing experiment: one workgroup per CU
+    constexpr int LDSB = 100 * 1024;
+#else
+    constexpr int LDSB = 2 * 2 * 32 * MT * D1W_HALVES * 128;
+#endif
     F2_HIP(ctx, hipFuncSetAttribute((const void*)k_dense1_ws<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-    const dim3 grid((unsigned)((n + 32 * MT - 1) / (32 * MT)), (D1W_TILES + D1W_WAVES - 1) / D1W_WAVES);
-    hipLaunchKernelGGL(k_dense1_ws<MT>, grid, dim3(D1W_WAVES * 64), LDSB, ctx->stream, a4,
-                       (const h16x8*)(cnn->blob16 + cnn->off16[3]), cnn->t(9), a5, K, n, cnn->sc);
+    const int64_t nrb = (n + 32 * MT * D1W_HALVES - 1) / (32 * MT * D1W_HALVES);
+    const dim3 grid((unsigned)((nrb + 7) / 8 * 8 * D1W_GROUPS));
+#ifdef F2_WS_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    if (!d_stamps) F2_HIP(ctx, hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 8 * 8 * 32 * 8));
+    F2_HIP(ctx, hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * 8 * 8 * 32 * 8, ctx->stream));
+#endif
+    hipLaunchKernelGGL(k_dense1_ws<MT>, grid, dim3(D1W_THREADS), LDSB, ctx->stream, a4,
+                       (const h16x8*)(cnn->blob16 + cnn->off16[3]), cnn->t(9), a5, K, n, cnn->sc WS_STAMP_PASS);
     F2_HIP(ctx, hipGetLastError());
+#ifdef F2_WS_STAMPS
+    ws_stamp_report(ctx, "k_dense1_ws (waves 0-7 of 12; chunk = iteration: +matrix loop = wait for the first weight fragment, +epilogue = four steps issued, slot4 = split + stores done, +barrier = through the barrier)", d_stamps);
+#endif
     return F2_OK;
 }
