@@ -718,10 +718,11 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
 // odd rows, whose halves of the 256-byte bank window are fixed by the row's parity). (conv4 leaving its outputs already split - two
 // 2-byte stores or one packed dword per value - was measured too: it takes 18 us out of this kernel's staging and puts them into
 // k_conv34_ws's combine, which runs beside matrix loops.)
-// Workgroup shape (round 5, profiles/r05_dense1_*.txt): a workgroup's waves go to SIMD (wave % 4), every workgroup starting at SIMD
-// 0, so two resident 6-wave workgroups loaded the SIMDs 4, 4, 2, 2 - with every other cost knocked out the kernel stood at the
-// matrix time of the 4-wave SIMDs (98 of 122 us per 14 240 windows). Now 12 waves = 2 row halves x 6 output tiles: three waves
-// per SIMD, one workgroup per CU, 164 registers. What is left (113 us against 58 us of matrix time): the activation fragments -
+// Workgroup shape (round 5, profiles/r05_dense1_knockouts.txt): with two resident 6-wave workgroups per CU and every other cost
+// knocked out the kernel took 98 of its 122 us per 14 240 windows - the matrix time of a SIMD that runs FOUR of the CU's twelve
+// waves, and the same with one workgroup per CU in two rounds: the times fit both workgroups' waves going 2, 2, 1, 1 to the
+// SIMDs (the two-wave workgroups of the filterbank kernel do spread: 4 waves per workgroup change nothing there). Now 12 waves =
+// 2 row halves x 6 output tiles: three waves per SIMD by construction, one workgroup per CU, 164 registers. What is left (113 us against 58 us of matrix time): the activation fragments -
 // 2 KB of LDS reads per 3 MT MFMAs and wave, 22 us with everything else knocked out - and the launch's fixed costs.
 constexpr int D1W_WAVES = 6, D1W_KC = 64, D1W_TILES = 17, D1W_NPAD = D1W_TILES * 32, D1W_N = 516;
 constexpr int D1W_GROUPS = (D1W_TILES + D1W_WAVES - 1) / D1W_WAVES;
