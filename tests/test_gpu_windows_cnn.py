@@ -225,13 +225,14 @@ def test_cnn_split_path_scales_follow_the_weights():
 
 @pytest.mark.parametrize("rows,channels", [(11, 128), (10, 100)])
 def test_cnn_weight_stationary_kernels_at_awkward_window_counts(rows, channels):
-    """The persistent kernels walk (window, column tile) tasks with a stride of the grid and dense1 takes 96 windows per workgroup:
-    window counts that leave a workgroup zero, one or two tasks, a partial last dense tile, or exactly a tile - against the
-    per-tile kernels (the same split arithmetic in conv2-conv4, float32 conv1: within 5e-7) and the oracle."""
+    """The persistent kernels walk (window, column tile) tasks with a stride of the grid and dense1 takes 2 x 96 windows per
+    workgroup, row blocks dealt out in groups of eight: window counts that leave a workgroup zero, one or two tasks, an empty
+    second half, a partial last dense tile, exactly a tile, a group of row blocks with one block more or less - against the per-tile
+    kernels (the same split arithmetic in conv2-conv4, float32 conv1: within 5e-7) and the oracle."""
     ctx = _lib.default_context()
     m = F2CNNModel.glorot(3, rows, channels, zero_bias=False)
     rng = np.random.default_rng(12)
-    for n in (1, 2, 63, 95, 96, 97, 193, 300, 1025):
+    for n in (1, 2, 63, 95, 96, 97, 191, 192, 193, 300, 385, 1025, 1535, 1537):
         x = rng.random((n, rows, channels)).astype(np.float32)
         got = m.predict(x, ctx)
         try:

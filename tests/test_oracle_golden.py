@@ -159,3 +159,26 @@ def test_cnn_forward_shapes_and_softmax():
     assert s.shape == (5, 2) and s.dtype == np.float32
     np.testing.assert_allclose(s.sum(axis=1), 1, rtol=1e-6)
     assert orc.labels_from_scores(np.array([[0.5, 0.5], [0.2, 0.8], [0.9, 0.1]])).tolist() == [0, 1, 0]
+
+
+@pytest.mark.parametrize("rows,channels", [(11, 128), (13, 40), (10, 100)])
+def test_cnn_forward_against_an_independent_operator_library(rows, channels):
+    """No Keras exists here to pin the CNN restatement, so it is at least held against a second,
+    independent implementation of the operators Training.py:93-114 names: torch.nn.functional's conv2d ('same' = one zero
+    pixel, 'valid' = none), max_pool2d(2) (floor), channels-last Flatten, linear, softmax - float32 on the CPU."""
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    w = orc.glorot_weights(3, nchannels=channels, rows=rows, zero_bias=False)
+    x = np.random.default_rng(8).random((7, rows, channels)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    conv = lambda h, name, pad: F.conv2d(h, t(w[name + "_w"].transpose(3, 2, 0, 1)), t(w[name + "_b"]), padding=pad)   # HWIO -> OIHW
+    with torch.no_grad():
+        h = t(x)[:, None]                                        # NCHW, one input channel
+        h = F.relu(conv(h, "conv1", 1))
+        h = F.max_pool2d(F.relu(conv(h, "conv2", 0)), 2)
+        h = F.relu(conv(h, "conv3", 1))
+        h = F.max_pool2d(F.relu(conv(h, "conv4", 0)), 2)
+        h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)        # Keras flattens (H, W, C)
+        h = F.relu(h @ t(w["dense1_w"]) + t(w["dense1_b"]))
+        s = F.softmax(h @ t(w["dense2_w"]) + t(w["dense2_b"]), dim=1).numpy()
+    np.testing.assert_allclose(orc.cnn_forward(x, w), s, atol=2e-6)
