@@ -80,7 +80,7 @@ int f2_upload_async(f2_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
         ev = ctx->prof_pool.back();
         ctx->prof_pool.pop_back();
     } else {
-        F2_HIP(ctx, hipEventCreate(&ev));
+        F2_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));   // (shares the pool of the timing events: the device only READS the guarded buffer)
     }
     // (from here on an early return hands `ev` back to the pool)
     struct ev_guard {
@@ -125,7 +125,9 @@ static int prof_event(f2_ctx* ctx, hipEvent_t* ev) {
         ctx->prof_pool.pop_back();
         return F2_OK;
     }
-    F2_HIP(ctx, hipEventCreate(ev));
+    // (timing events only: without the system-scope fence - a cache write-back of ~10 us between two kernels - that a default
+    // event performs when it is reached; the events of f2_event_create, which order host reads after device writes, keep it)
+    F2_HIP(ctx, hipEventCreateWithFlags(ev, hipEventDisableSystemFence));
     return F2_OK;
 }
 
