@@ -381,21 +381,21 @@ class DspJob:
         self.ctx.free(self.d_out)
 
 
-def timed(ctx, ranks, step, steps, warmup, events=True):
-    """W untimed steps, barrier + device sync, K timed steps, device sync. Returns (elapsed_s, prof). `events`: the library
-    brackets every kernel group with HIP events inside the timed region (what `roofline.achieved` is made of); a step of many
-    short launches (cfg4: 34 event pairs, ~8 us of idle GPU each) is timed without them and split in a second pass."""
+def timed(ctx, ranks, step, steps, warmup):
+    """W untimed steps, barrier + device sync, K timed steps, device sync. Returns (elapsed_s, prof): the library brackets every
+    kernel group with HIP events inside the timed region (what `roofline.achieved` is made of; measured on cfg4, 34 event pairs
+    per step: a pass without them is no faster)."""
     for _ in range(warmup):
         step()
     ctx.synchronize()
     ranks.barrier()
-    ctx.prof_enable(bool(events))
+    ctx.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
-    prof = ctx.prof_get() if events else {}
+    prof = ctx.prof_get()
     ctx.prof_enable(False)
     return elapsed, prof
 
@@ -546,8 +546,7 @@ def block_cfg4(ctx, coefs, precision, B, N, steps, warmup, ranks, with_cpu):
     def step():
         ctx.eval_batch(hcnn, d_wave, _lib.WAVE_I16, offsets, coefs, B, 128, False, 0.0, precision, 5, 160, d_scores,
                        d_labels, _lib.MEM_DEVICE)
-    elapsed, _ = timed(ctx, ranks, step, steps, warmup, events=False)
-    elapsed_ev, prof = timed(ctx, ranks, step, steps, 0)       # second pass, same steps: the per-kernel split
+    elapsed, prof = timed(ctx, ranks, step, steps, warmup)
     for p in (d_wave, d_scores, d_labels):
         ctx.free(p)
     cnn_s = prof["k_cnn_forward"][1] / 1e3
@@ -555,7 +554,7 @@ def block_cfg4(ctx, coefs, precision, B, N, steps, warmup, ranks, with_cpu):
     out = {"workload": f"cfg4: cnn eval end to end (filterbank, envelope, every-sample 11x128 windows, normalise, CNN), "
                        f"{B} x {N / FS:g} s utterances per GPU = {B * nb} windows, Glorot weights seed 7",
            "value": round(B * N / FS * steps / elapsed, 2), "unit": "audio-seconds/s", "steps": steps,
-           "ms_per_step": round(elapsed / steps * 1e3, 3), "ms_per_step_with_kernel_events": round(elapsed_ev / steps * 1e3, 3),
+           "ms_per_step": round(elapsed / steps * 1e3, 3),
            "cnn": {"launch_groups": prof["k_cnn_forward"][0], "ms_per_step": round(cnn_s / steps * 1e3, 3),
                    **cnn_accounting(ctx, flop, cnn_s, nb * B * steps)},
            "kernels_ms_per_step": {k: round(ms / steps, 3) for k, (n, ms) in prof.items()}}
@@ -808,9 +807,7 @@ def main():
                                 "algorithmic_GFLOPps": round(flop / cnn_s / 1e9, 1),
                                 "algorithmic_flop_per_launch": flop // prof["k_cnn_forward"][0],
                                 "avg_launch_ms": round(cnn_s * 1e3 / prof["k_cnn_forward"][0], 4),
-                                "launches_timed": prof["k_cnn_forward"][0],
-                                "events": "a second pass over the same steps (the timed one runs without the 34 event pairs per step: "
-                                          f"{blk['ms_per_step_with_kernel_events']} ms per step with them)"},
+                                "launches_timed": prof["k_cnn_forward"][0]},
                    "kernels": blk["kernels_ms_per_step"], "cpu_baseline": blk.get("cpu_baseline")}
             if out["cpu_baseline"]:
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
