@@ -40,10 +40,35 @@ __device__ __forceinline__ void split_h16(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
+// Two values at a time: the hi pieces by one packed conversion, each lo piece by one mixed-precision FMA that reads its fp16
+// hi piece straight from the packed register and rounds v - hi to fp16 into its half of the result (v_fma_mixlo / mixhi_f16):
+// 3 instructions per pair where the compiler's rendering of the C expressions below takes 6-7 (it converts every hi piece back
+// to float32 and subtracts there). Bit-identical to them over 8.4 M values incl. subnormal pieces (tools/ubench/split_mix_check.hip).
+__device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo) {
+#ifdef F2_SPLIT_PLAIN    // (the C form, for A/B builds)
+    typedef _Float16 h16x2_ __attribute__((ext_vector_type(2)));
+    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+    hi = __builtin_bit_cast(unsigned, h16x2_{h0, h1});
+    lo = __builtin_bit_cast(unsigned, h16x2_{(_Float16)(v0 - (float)h0), (_Float16)(v1 - (float)h1)});
+#else
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v1));
+#endif
+}
+
 __device__ __forceinline__ void split4(const float v0, const float v1, const float v2, const float v3, h16x4& hi, h16x4& lo) {
-    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;
-    hi = h16x4{h0, h1, h2, h3};
-    lo = h16x4{(_Float16)(v0 - (float)h0), (_Float16)(v1 - (float)h1), (_Float16)(v2 - (float)h2), (_Float16)(v3 - (float)h3)};
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    u32x2_ h, l;
+    unsigned a, b;
+    split2(v0, v1, a, b);
+    h[0] = a;
+    l[0] = b;
+    split2(v2, v3, a, b);
+    h[1] = a;
+    l[1] = b;
+    hi = __builtin_bit_cast(h16x4, h);
+    lo = __builtin_bit_cast(h16x4, l);
 }
 
 #endif

@@ -349,12 +349,11 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
         } else if (c == 1) {
             w1h = *reinterpret_cast<const h16x8*>(ldsW1);
             w1l = *reinterpret_cast<const h16x8*>(ldsW1 + 64 * 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 vh = (_Float16)xv[j];
-                xh[j] = vh;
-                xl[j] = (_Float16)(xv[j] - (float)vh);
-            }
+            h16x4 h0, l0, h1, l1;
+            split4(xv[0], xv[1], xv[2], xv[3], h0, l0);
+            split4(xv[4], xv[5], xv[6], xv[7], h1, l1);
+            xh = h16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            xl = h16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         } else if (c == 2) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) a1[q] = 0.f;
@@ -407,16 +406,16 @@ __global__ __launch_bounds__(512) void k_conv12_ws(const float* __restrict__ x, 
         tile_split(blockIdx.x + (unsigned)k * G, xt, win, xi0);
         const int x0 = 32 * (int)xi0 + 16 * ch;
         _Float16* o = out + ((size_t)(win * 4 + rp) * (size_t)Wa + (size_t)((x0 >> 1) + 2 * h)) * 64 + i;
-#pragma unroll
-        for (int kk = kk0; kk < kk0 + 2; ++kk) {
-            const int q = 2 * kk;
-            const int dpx = ((q & 3) + 8 * (q >> 2)) >> 1;                     // 0, 1, 4, 5
-            const float v = relu(fmaf(pm[kk], c2, bias));
-            const _Float16 vh = (_Float16)v;
-            const _Float16 vl = (_Float16)(v - (float)vh);
-            o[dpx * 64] = vh;
-            o[dpx * 64 + 32] = vl;
-        }
+        // (the pair kk0, kk0 + 1 split together; pixels 0, 1 / 4, 5 of the lane's four)
+        typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+        unsigned ph2, pl2;
+        split2(relu(fmaf(pm[kk0], c2, bias)), relu(fmaf(pm[kk0 + 1], c2, bias)), ph2, pl2);
+        const h16x2 vh = __builtin_bit_cast(h16x2, ph2), vl = __builtin_bit_cast(h16x2, pl2);
+        const int dpx = kk0 == 0 ? 0 : 4;
+        o[dpx * 64] = vh[0];
+        o[dpx * 64 + 32] = vl[0];
+        o[(dpx + 1) * 64] = vh[1];
+        o[(dpx + 1) * 64 + 32] = vl[1];
     };
 
     bool pending = false;                                      // pm holds the maxima of task t_(k-1), not stored yet
@@ -594,6 +593,8 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
                     const int pb = (2 * rp + mt) * PW + i;
                     const int base = b64_off(pb, 2 * nt) + 8 * h;   // chunk 2 nt + (g & 1) of plane g >> 1: base ^ ((g & 1) << 4)
                     h16x4 vh, vl;
+                    // (scalar multiplies: a v_pk_mul_f32 per pair made this kernel 4 % slower, the multiplication folded into the
+                    // v_fma_mix conversions changed nothing - profiles/r05_valu_diet.txt)
                     split4(relu(acc[mt][4 * g]) * c3, relu(acc[mt][4 * g + 1]) * c3, relu(acc[mt][4 * g + 2]) * c3,
                            relu(acc[mt][4 * g + 3]) * c3, vh, vl);
                     const int off = (g >> 1) * PB_PLANE + (base ^ ((g & 1) << 4));

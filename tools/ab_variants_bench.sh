@@ -10,6 +10,6 @@ for v in "$@"; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_${v}.json")); k=d.get("kernels", {})
-print("$v", d["value"], d["ms_per_step"], {n:round(x["ms_per_step"],3) for n,x in k.items()}, flush=True)
+print("$v", d["value"], d["ms_per_step"], {n:round(x["ms_per_step"] if isinstance(x, dict) else x,3) for n,x in k.items()}, flush=True)
 PY
 done; done | tee gpurun_out/${tag}_ab_bench.txt
