@@ -44,6 +44,9 @@ __device__ __forceinline__ void split_h16(float v, _Float16& hi, _Float16& lo) {
 // hi piece straight from the packed register and rounds v - hi to fp16 into its half of the result (v_fma_mixlo / mixhi_f16):
 // 3 instructions per pair where the compiler's rendering of the C expressions below takes 6-7 (it converts every hi piece back
 // to float32 and subtracts there). Bit-identical to them over 8.4 M values incl. subnormal pieces (tools/ubench/split_mix_check.hip).
+// Inline asm is invisible to the compiler's hazard recogniser: the operands must NOT be matrix-core results still in flight (every
+// caller passes the output of a ReLU or a multiply, i.e. of a compiler-scheduled VALU instruction that already waited for them) -
+// a v_max3 written this way straight on the accumulators read them too early and the create-time self-check switched the kernels off.
 __device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo) {
 #ifdef F2_SPLIT_PLAIN    // (the C form, for A/B builds)
     typedef _Float16 h16x2_ __attribute__((ext_vector_type(2)));

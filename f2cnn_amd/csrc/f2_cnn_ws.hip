@@ -624,7 +624,12 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
         }
     } else {
         // ---------------- loader + conv4: output tile nt, K half kh (input channels 32 kh .. 32 kh + 31) ----------------
-        const int cw = wave - 4, nt = cw & 1, kh = cw >> 1;
+        // (kh selects accumulator REGISTERS below - the half of them this wave finishes - so it has to be a compile-time constant:
+        // as a wave-uniform run-time value every such access became an s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off triple, 64 moves
+        // and 128 mode switches per tile; the role is instantiated for both halves and chosen by a wave-uniform branch)
+        const int cw = wave - 4, nt = cw & 1;
+        auto conv4_role = [&](auto KH) {
+        constexpr int kh = decltype(KH)::value;
         h16x8 wh[18], wl[18];
         {
             const h16x8* ph = w4s + h * C4 + nt * 32 + i;    // [piece][tap][kb (4)][h][cout]
@@ -704,6 +709,9 @@ __global__ __launch_bounds__(512) void k_conv34_ws(const uint4* __restrict__ in,
             __syncthreads();
             WS_STAMP(j, 3);
         }
+        };
+        if (cw >> 1) conv4_role(std::integral_constant<int, 1>{});
+        else conv4_role(std::integral_constant<int, 0>{});
     }
 }
 
