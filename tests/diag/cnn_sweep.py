@@ -1,4 +1,4 @@
-"""Randomised check of the default (split-bf16) CNN path against the oracle CNN (float32, Training.py:93-114): several
+"""Randomised check of the default (split-fp16; split-bf16 in rounds 3-4) CNN path against the oracle CNN (float32, Training.py:93-114): several
 weight seeds, input shapes and input statistics. Diagnostic, GPU box only."""
 import os, sys
 import numpy as np
